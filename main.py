@@ -1,0 +1,159 @@
+"""Distributed data-parallel training script (MI355X-native).
+
+Same CLI and behaviour as the reference script (``/root/reference/main.py``):
+
+    python -m pytorch_distributed_training_amd.launch --nproc_per_node=8 main.py \
+        --batch_size 128 --JobID Job0
+
+* ``--local_rank`` (also ``--local-rank`` / ``LOCAL_RANK``), ``--batch_size``
+  (per-GPU, default 128), ``--JobID`` (default "Job0"); ``epochs=2``,
+  ``lr=0.001`` by default (``main.py:23-32``).
+* env:// process group, one process per GPU (``main.py:34-37``).
+* ResNet-50 with a 1000-way head on CIFAR-100-shaped data, DistributedSampler
+  + pinned loader, Adam + mean cross-entropy, SyncBatchNorm, DDP
+  (``main.py:40-63,79-84``).
+* Loop order forward -> loss -> zero_grad -> backward -> step -> loss reduce
+  (``main.py:100-105``); per-rank TSV log and rank-0 prints with the same
+  names, formulas and cadence (``main.py:65-67,107-117``); profiler wait 2 /
+  warmup 2 / active 6 into ``./log_{JobID}`` (``main.py:70-78,115``).
+
+Opt-in additions (defaults reproduce the reference): model / dataset / dtype /
+optimizer choice, step cap, checkpoint + resume, profile mode, JSON summary.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import pytorch_distributed_training_amd as pdt  # noqa: E402
+from pytorch_distributed_training_amd import dist as pdist  # noqa: E402
+from pytorch_distributed_training_amd.data import DataLoader, DistributedSampler, build_dataset  # noqa: E402
+from pytorch_distributed_training_amd.engine import Engine, EngineConfig  # noqa: E402
+from pytorch_distributed_training_amd.utils import checkpoint as ckpt  # noqa: E402
+from pytorch_distributed_training_amd.utils import metrics, profiling  # noqa: E402
+
+
+def get_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="MI355X-native DDP training (reference-compatible CLI)")
+    # --- the reference's three flags (main.py:23-26) ---
+    p.add_argument("--local_rank", "--local-rank", dest="local_rank", type=int, default=None, help="local gpu id")
+    p.add_argument("--batch_size", default=128, type=int, help="batch size (per GPU)")
+    p.add_argument("--JobID", default="Job0", type=str, help="JOB ID")
+    # --- opt-in extras; defaults reproduce the reference ---
+    p.add_argument("--epochs", default=2, type=int)
+    p.add_argument("--lr", default=0.001, type=float)
+    p.add_argument("--model", default="resnet50",
+                   choices=["resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "vit_b_16", "vit_tiny_test"])
+    p.add_argument("--dataset", default="cifar100",
+                   choices=["cifar100", "synthetic-cifar", "synthetic-cifar10", "synthetic-imagenet"])
+    p.add_argument("--data_root", default="dataset", type=str)
+    p.add_argument("--dataset_len", default=None, type=int, help="override the dataset length (synthetic sets)")
+    p.add_argument("--num_classes", default=1000, type=int, help="width of the classifier head (reference: 1000)")
+    p.add_argument("--optimizer", default="adam", choices=["adam", "adamw", "sgd"])
+    p.add_argument("--momentum", default=0.9, type=float)
+    p.add_argument("--weight_decay", default=0.0, type=float)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="GPU compute dtype")
+    p.add_argument("--sync_bn", dest="sync_bn", action="store_true", default=True)
+    p.add_argument("--no_sync_bn", dest="sync_bn", action="store_false")
+    p.add_argument("--bucket_cap_mb", default=None, type=float)
+    p.add_argument("--backend", default=None, choices=["rccl", "nccl", "gloo"])
+    p.add_argument("--steps", default=None, type=int, help="stop after this many iterations (benchmarks)")
+    p.add_argument("--checkpoint", default=None, type=str, help="save a checkpoint here at the end of each epoch")
+    p.add_argument("--checkpoint_every", default=0, type=int, help="also save every N steps")
+    p.add_argument("--resume", default=None, type=str)
+    p.add_argument("--profile", default="torch", choices=["none", "torch", "roctx"])
+    p.add_argument("--seed", default=None, type=int)
+    p.add_argument("--eval", action="store_true", help="run the top-1 evaluation after training (main.py:119-130)")
+    p.add_argument("--summary_json", default=None, type=str)
+    p.add_argument("--log_dir", default=".", type=str)
+    return p
+
+
+def main(argv=None) -> int:
+    args = get_parser().parse_args(argv)
+    batch_size, job_id, epochs = args.batch_size, args.JobID, args.epochs
+
+    env = pdist.init_process_group(backend=args.backend, init_method="env://", local_rank=args.local_rank)
+    global_rank, world_size = env.rank, env.world_size
+
+    trainset = build_dataset(args.dataset, train=True, root=args.data_root, length=args.dataset_len)
+    valset = build_dataset(args.dataset, train=False, root=args.data_root,
+                           length=None if args.dataset_len is None else max(1, args.dataset_len // 5))
+    sampler = DistributedSampler(trainset)
+    train_loader = DataLoader(trainset, batch_size=batch_size, shuffle=False, pin_memory=True, sampler=sampler,
+                              device=env.device)
+    val_sampler = DistributedSampler(valset, shuffle=False)
+    val_loader = DataLoader(valset, batch_size=batch_size, shuffle=False, pin_memory=True, sampler=val_sampler,
+                            device=env.device)
+
+    log = metrics.ThroughputLog(job_id, batch_size, global_rank, world_size, args.log_dir)
+    timer = metrics.StepTimer()
+
+    with profiling.make_profiler(args.profile, job_id) as prof:
+        engine = Engine(EngineConfig(
+            model=args.model, num_classes=args.num_classes, dtype=args.dtype, optimizer=args.optimizer, lr=args.lr,
+            momentum=args.momentum, weight_decay=args.weight_decay, sync_bn=args.sync_bn,
+            bucket_cap_mb=args.bucket_cap_mb, seed=args.seed,
+            image_size=trainset.sample_shape[1]))
+        start_epoch, global_step = 0, 0
+        if args.resume:
+            st = ckpt.load_checkpoint(args.resume, engine.net, engine.optimizer, sampler)
+            start_epoch, global_step = st["epoch"], st["global_step"]
+        print("Start")
+        log.train_begin = time.time()
+        done = False
+        for e in range(start_epoch, epochs):
+            sampler.set_epoch(e)
+            for idx, (imgs, labels) in enumerate(train_loader):
+                start = time.time()
+                global_step += 1
+                loss = engine.train_step(imgs, labels)
+                pdist.reduce_loss(loss, global_rank, world_size)
+
+                if log.should_log(global_step):
+                    loss_value = loss.item()
+                    log.row(global_step, loss_value, time.time() - start)
+                if idx % 10 == 0 and global_rank == 0:
+                    print("Epoch: {} step: {} loss: {}".format(e, idx, loss.item()))
+                prof.step()
+                timer.add(time.time() - start)
+                if args.checkpoint and args.checkpoint_every and global_step % args.checkpoint_every == 0:
+                    ckpt.save_checkpoint(args.checkpoint, engine.net, engine.optimizer, e, global_step, sampler)
+                if args.steps is not None and global_step >= args.steps:
+                    done = True
+                    break
+            if args.checkpoint:
+                ckpt.save_checkpoint(args.checkpoint, engine.net, engine.optimizer, e + 1, global_step, sampler)
+            if done:
+                break
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        log.footer()
+
+        if args.eval:
+            acc = engine.evaluate(val_loader)
+            if global_rank == 0:
+                print("eval accuracy: {}".format(acc))
+
+    if args.summary_json and global_rank == 0:
+        from pytorch_distributed_training_amd.nn import functional as pF
+
+        s = timer.summary(batch_size * world_size)
+        s.update({"world_size": world_size, "batch_size": batch_size, "model": args.model, "dataset": args.dataset,
+                  "dtype": str(engine.dtype), "reducer": engine.net.reducer_kind,
+                  "native_extension": pdt.native_available(),
+                  "library_fallbacks": dict(pF.fallback_counts)})
+        metrics.write_json(args.summary_json, s)
+    log.close()
+    pdist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

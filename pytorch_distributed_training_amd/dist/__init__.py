@@ -1,0 +1,159 @@
+"""Process-group bootstrap and the few explicit collectives of the reference.
+
+Reference behaviour (``/root/reference/main.py:34-37``)::
+
+    dist.init_process_group(backend='nccl', init_method='env://')
+    torch.cuda.set_device(args.local_rank)
+    global_rank = dist.get_rank(); world_size = dist.get_world_size()
+
+and ``reduce_loss`` (``main.py:16-20``).  Here the backend is selectable:
+``rccl`` (alias ``nccl``; RCCL over xGMI, one process per GPU) or ``gloo``
+(CPU plumbing, BASELINE.json config 1).  The rendezvous is ``env://``: rank 0
+hosts a TCP store on ``MASTER_ADDR:MASTER_PORT``.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as tdist
+
+_BACKEND_ALIASES = {"rccl": "nccl", "nccl": "nccl", "gloo": "gloo"}
+
+
+@dataclass
+class DistEnv:
+    rank: int
+    world_size: int
+    local_rank: int
+    backend: str  # "rccl" or "gloo" (our naming)
+    device: torch.device
+
+    @property
+    def is_main(self) -> bool:
+        return self.rank == 0
+
+
+_ENV: DistEnv | None = None
+
+
+def resolve_local_rank(cli_value: int | None = None) -> int:
+    """``--local_rank`` / ``--local-rank`` / ``LOCAL_RANK``."""
+    if cli_value is not None:
+        return int(cli_value)
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def default_backend() -> str:
+    return "rccl" if torch.cuda.is_available() else "gloo"
+
+
+def init_process_group(
+    backend: str | None = None,
+    init_method: str = "env://",
+    local_rank: int | None = None,
+    timeout_s: float | None = None,
+) -> DistEnv:
+    """Initialise the default group; process group first, then device selection
+    (the order of ``main.py:34-35``)."""
+    global _ENV
+    backend = (backend or default_backend()).lower()
+    if backend not in _BACKEND_ALIASES:
+        raise ValueError(f"unknown backend {backend!r}; choose rccl (alias nccl) or gloo")
+    torch_backend = _BACKEND_ALIASES[backend]
+    if torch_backend == "nccl" and not torch.cuda.is_available():
+        raise RuntimeError("backend rccl needs a visible MI355X; use --backend gloo for CPU plumbing")
+    local_rank = resolve_local_rank(local_rank)
+
+    if init_method == "env://":
+        # Single-process convenience: fill the env contract the launcher would
+        # have provided so `python main.py` alone still works.
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+
+    kwargs = {}
+    if timeout_s is not None:
+        kwargs["timeout"] = datetime.timedelta(seconds=timeout_s)
+    if torch_backend == "nccl":
+        # bind the communicator to this rank's GPU up front (avoids the lazy
+        # "guess device from rank" path in ProcessGroupNCCL).
+        kwargs["device_id"] = torch.device("cuda", local_rank)
+    if not tdist.is_initialized():
+        tdist.init_process_group(backend=torch_backend, init_method=init_method, **kwargs)
+
+    if torch.cuda.is_available() and torch_backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
+    _ENV = DistEnv(
+        rank=tdist.get_rank(),
+        world_size=tdist.get_world_size(),
+        local_rank=local_rank,
+        backend="rccl" if torch_backend == "nccl" else "gloo",
+        device=device,
+    )
+    return _ENV
+
+
+def env() -> DistEnv:
+    if _ENV is None:
+        if tdist.is_initialized():
+            dev = torch.device("cuda", torch.cuda.current_device()) if (
+                torch.cuda.is_available() and tdist.get_backend() == "nccl") else torch.device("cpu")
+            return DistEnv(tdist.get_rank(), tdist.get_world_size(), resolve_local_rank(),
+                           "rccl" if tdist.get_backend() == "nccl" else "gloo", dev)
+        return DistEnv(0, 1, 0, "none", torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu"))
+    return _ENV
+
+
+def is_initialized() -> bool:
+    return tdist.is_available() and tdist.is_initialized()
+
+
+def get_rank() -> int:
+    return tdist.get_rank() if is_initialized() else 0
+
+
+def get_world_size() -> int:
+    return tdist.get_world_size() if is_initialized() else 1
+
+
+def barrier() -> None:
+    if is_initialized() and get_world_size() > 1:
+        if tdist.get_backend() == "nccl":
+            tdist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            tdist.barrier()
+
+
+def destroy_process_group() -> None:
+    global _ENV
+    if is_initialized():
+        tdist.destroy_process_group()
+    _ENV = None
+
+
+def reduce_loss(tensor: torch.Tensor, rank: int, world_size: int) -> None:
+    """``main.py:16-20``: SUM-reduce to rank 0, rank 0 divides by world size.
+
+    In place, under ``no_grad``; non-destination ranks keep whatever the
+    backend leaves in their buffer (their local loss for RCCL and gloo).
+    """
+    with torch.no_grad():
+        if is_initialized() and world_size > 1:
+            tdist.reduce(tensor, dst=0)
+        if rank == 0:
+            tensor /= world_size
+
+
+def all_reduce_mean_(tensor: torch.Tensor) -> torch.Tensor:
+    """Mean over ranks, in place (used by the synchronised metrics path)."""
+    if is_initialized() and get_world_size() > 1:
+        tdist.all_reduce(tensor)
+        tensor /= get_world_size()
+    return tensor

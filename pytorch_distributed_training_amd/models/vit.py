@@ -1,0 +1,123 @@
+"""ViT-B/16 (and friends) with torchvision-compatible ``state_dict`` keys.
+
+BASELINE.json config 5: "ViT-B/16 DDP bf16 (GEMM-heavy path, fused softmax-CE
++ SGD/AdamW)".  Keys: ``class_token``, ``conv_proj.{weight,bias}``,
+``encoder.pos_embedding``, ``encoder.layers.encoder_layer_{i}.{ln_1,ln_2}.*``,
+``...self_attention.{in_proj_weight,in_proj_bias,out_proj.weight,out_proj.bias}``,
+``...mlp.{0,3}.{weight,bias}``, ``encoder.ln.*``, ``heads.head.*``.
+
+197 tokens per image: ordinary single-device attention, no sequence
+parallelism.  The projections / MLP are plain GEMMs and go to
+the library (hipBLASLt); loss and optimizer are the fused HIP kernels.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as tnn
+import torch.nn.functional as tF
+
+from .. import nn as pnn
+
+
+class MultiheadSelfAttention(tnn.Module):
+    """Packed-QKV self attention, parameters named like ``nn.MultiheadAttention``."""
+
+    def __init__(self, dim: int, heads: int):
+        super().__init__()
+        assert dim % heads == 0
+        self.embed_dim, self.num_heads, self.head_dim = dim, heads, dim // heads
+        self.in_proj_weight = tnn.Parameter(torch.empty(3 * dim, dim))
+        self.in_proj_bias = tnn.Parameter(torch.zeros(3 * dim))
+        self.out_proj = pnn.Linear(dim, dim)
+        tnn.init.xavier_uniform_(self.in_proj_weight)
+        tnn.init.zeros_(self.out_proj.bias)
+
+    def forward(self, x):
+        b, s, d = x.shape
+        w, bias = self.in_proj_weight, self.in_proj_bias
+        if w.dtype != x.dtype:
+            qkv = pnn.modules._LowpLinearFn.apply(x, w, bias, getattr(w, "_lp", None))
+        else:
+            qkv = tF.linear(x, w, bias)
+        qkv = qkv.view(b, s, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]  # [b, h, s, hd]
+        att = torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(self.head_dim))
+        att = torch.softmax(att.float(), dim=-1).to(x.dtype)
+        out = torch.matmul(att, v).transpose(1, 2).reshape(b, s, d)
+        return self.out_proj(out)
+
+
+class EncoderBlock(tnn.Module):
+    def __init__(self, dim, heads, mlp_dim, dropout=0.0):
+        super().__init__()
+        self.ln_1 = tnn.LayerNorm(dim, eps=1e-6)
+        self.self_attention = MultiheadSelfAttention(dim, heads)
+        self.dropout = tnn.Dropout(dropout)
+        self.ln_2 = tnn.LayerNorm(dim, eps=1e-6)
+        self.mlp = tnn.Sequential(
+            pnn.Linear(dim, mlp_dim), tnn.GELU(), tnn.Dropout(dropout), pnn.Linear(mlp_dim, dim), tnn.Dropout(dropout))
+        for m in (self.mlp[0], self.mlp[3]):
+            tnn.init.xavier_uniform_(m.weight)
+            tnn.init.normal_(m.bias, std=1e-6)
+
+    @staticmethod
+    def _ln(ln, x):
+        return tF.layer_norm(x.float(), ln.normalized_shape, ln.weight.float(), ln.bias.float(), ln.eps).to(x.dtype)
+
+    def forward(self, x):
+        y = self.dropout(self.self_attention(self._ln(self.ln_1, x)))
+        x = x + y
+        return x + self.mlp(self._ln(self.ln_2, x))
+
+
+class Encoder(tnn.Module):
+    def __init__(self, seq_len, layers, heads, dim, mlp_dim, dropout=0.0):
+        super().__init__()
+        self.pos_embedding = tnn.Parameter(torch.empty(1, seq_len, dim).normal_(std=0.02))
+        self.dropout = tnn.Dropout(dropout)
+        self.layers = tnn.Sequential(OrderedDict(
+            (f"encoder_layer_{i}", EncoderBlock(dim, heads, mlp_dim, dropout)) for i in range(layers)))
+        self.ln = tnn.LayerNorm(dim, eps=1e-6)
+
+    def forward(self, x):
+        x = x + self.pos_embedding.to(x.dtype)
+        x = self.layers(self.dropout(x))
+        return EncoderBlock._ln(self.ln, x)
+
+
+class VisionTransformer(tnn.Module):
+    def __init__(self, image_size=224, patch_size=16, layers=12, heads=12, dim=768, mlp_dim=3072,
+                 num_classes=1000, dropout=0.0):
+        super().__init__()
+        assert image_size % patch_size == 0
+        self.image_size, self.patch_size, self.hidden_dim = image_size, patch_size, dim
+        self.conv_proj = pnn.Conv2d(3, dim, patch_size, patch_size)
+        seq = (image_size // patch_size) ** 2 + 1
+        self.class_token = tnn.Parameter(torch.zeros(1, 1, dim))
+        self.encoder = Encoder(seq, layers, heads, dim, mlp_dim, dropout)
+        self.heads = tnn.Sequential(OrderedDict(head=pnn.Linear(dim, num_classes)))
+        fan_in = 3 * patch_size * patch_size
+        tnn.init.trunc_normal_(self.conv_proj.weight, std=math.sqrt(1.0 / fan_in))
+        tnn.init.zeros_(self.conv_proj.bias)
+        tnn.init.zeros_(self.heads.head.weight)
+        tnn.init.zeros_(self.heads.head.bias)
+
+    def forward(self, x):
+        b = x.shape[0]
+        x = self.conv_proj(x)  # [b, dim, h/p, w/p]
+        x = x.flatten(2).transpose(1, 2)  # [b, tokens, dim]
+        x = torch.cat([self.class_token.to(x.dtype).expand(b, -1, -1), x], dim=1)
+        x = self.encoder(x)
+        return self.heads(x[:, 0])
+
+
+def vit_b_16(num_classes=1000, image_size=224, **kw):
+    return VisionTransformer(image_size, 16, 12, 12, 768, 3072, num_classes, **kw)
+
+
+def vit_tiny_test(num_classes=10, image_size=32, **kw):
+    """A 2-layer toy of the same architecture for CPU tests."""
+    return VisionTransformer(image_size, 8, 2, 2, 32, 64, num_classes, **kw)

@@ -1,0 +1,270 @@
+"""Autograd functions over the op layer (HIP kernels on GPU, oracles on CPU).
+
+One training step of the reference (``/root/reference/main.py:100-104``) runs
+53 conv + 53 BN + 49 ReLU + 16 residual adds + pools + fc + CE through stock
+ATen/cuDNN kernels.  Here the graph is coarser: every
+``conv -> BN -> (+residual) -> ReLU`` group is two autograd nodes
+
+* ``conv2d``      implicit-GEMM conv; its epilogue also emits the per-channel
+                  ``[sum, sum_sq]`` BN statistics of its own output (no extra
+                  pass over the activation);
+* ``bn_act``      normalise + affine (+ residual add) (+ ReLU) in one pass;
+                  backward fuses the ReLU mask into the BN reductions.
+
+SyncBatchNorm is the same node with one all-reduce of ``[sum, sum_sq, count]``
+in forward and one of ``[sum_dy, sum_dy_xhat]`` in backward (all-reduce-of-sums
+formulation: no host sync, so the step stays graph-capturable; SURVEY §2.5
+S4a/S4b).  Works on CPU tensors over gloo, which stock SyncBatchNorm refuses.
+"""
+from __future__ import annotations
+
+import collections
+
+import torch
+import torch.distributed as tdist
+
+from ..ops import backend_for, reference
+
+fallback_counts: collections.Counter = collections.Counter()
+
+
+def _note_fallback(op: str, why: str) -> None:
+    fallback_counts[f"{op}: {why}"] += 1
+
+
+def _cl(t: torch.Tensor) -> torch.Tensor:
+    """channels_last-contiguous view/copy of a 4-D GPU tensor (no-op on CPU)."""
+    if t.is_cuda and t.dim() == 4 and not t.is_contiguous(memory_format=torch.channels_last):
+        return t.contiguous(memory_format=torch.channels_last)
+    return t
+
+
+# --------------------------------------------------------------------- conv
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, w_lp, stride, padding, want_stats):
+        wk = w_lp if w_lp is not None else w
+        be = backend_for(x)
+        x = _cl(x)
+        if be is not reference:
+            why = be.conv_unsupported_reason(x, wk, stride, padding)
+            if why is not None:
+                _note_fallback("conv2d", why)
+                be = reference
+        y, stats = be.conv2d_fwd(x, wk, stride, padding, want_stats)
+        ctx.save_for_backward(x, wk)
+        ctx.cfg = (be, stride, padding, tuple(w.shape), w.dtype)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, wk = ctx.saved_tensors
+        be, stride, padding, w_shape, w_dtype = ctx.cfg
+        dy = _cl(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = be.conv2d_dgrad(dy, wk, tuple(x.shape), stride, padding)
+        if ctx.needs_input_grad[1]:
+            dw = be.conv2d_wgrad(dy, x, w_shape, stride, padding)
+            if dw.dtype != w_dtype:
+                dw = dw.to(w_dtype)
+        return dx, dw, None, None, None, None
+
+
+def conv2d(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = False):
+    """Bias-free square-stride conv.  Returns ``(y, stats)`` where ``stats`` is the
+    fp32 ``[2, Cout]`` per-channel ``[sum, sum_sq]`` of ``y`` (or ``None``)."""
+    w_lp = getattr(weight, "_lp", None)
+    if w_lp is not None and w_lp.dtype != x.dtype:
+        w_lp = None
+    return _Conv2dFn.apply(x, weight, w_lp, int(stride), int(padding), bool(want_stats))
+
+
+# ---------------------------------------------------------------- batchnorm
+class BNConfig:
+    """Per-layer BN state handed to the autograd node (not tensors of the graph)."""
+
+    __slots__ = ("running_mean", "running_var", "num_batches_tracked", "momentum", "eps", "training",
+                 "sync", "group")
+
+    def __init__(self, running_mean, running_var, num_batches_tracked, momentum, eps, training, sync=False,
+                 group=None):
+        self.running_mean, self.running_var = running_mean, running_var
+        self.num_batches_tracked = num_batches_tracked
+        self.momentum, self.eps, self.training = momentum, eps, training
+        self.sync, self.group = sync, group
+
+
+def _sync_world(cfg: BNConfig) -> int:
+    if not cfg.sync or not (tdist.is_available() and tdist.is_initialized()):
+        return 1
+    return tdist.get_world_size(cfg.group)
+
+
+class _BNActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, stats, cfg: BNConfig, relu: bool):
+        be = backend_for(x)
+        x = _cl(x)
+        if residual is not None:
+            residual = _cl(residual)
+        if be is not reference:
+            why = be.bn_unsupported_reason(x)
+            if why is not None:
+                _note_fallback("bn_act", why)
+                be = reference
+        world = _sync_world(cfg)
+        b, c, h, w = x.shape
+        count = float(b * h * w)
+        count_t = None
+        if cfg.training:
+            if stats is None:
+                stats = be.bn_stats(x)
+            if world > 1:
+                # [sum(C), sum_sq(C), count]: one all-reduce, counts may differ per rank
+                packed = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)
+                packed[: 2 * c].copy_(stats.reshape(-1))
+                packed[2 * c] = count
+                tdist.all_reduce(packed, group=cfg.group)
+                stats = packed[: 2 * c].view(2, c)
+                count_t = packed[2 * c:]
+            cnt = count_t if count_t is not None else count
+            mean, invstd = be.bn_finalize(stats, cnt, cfg.eps)
+            if cfg.running_mean is not None:
+                if cfg.num_batches_tracked is not None:
+                    cfg.num_batches_tracked.add_(1)
+                mom = cfg.momentum
+                if mom is None:  # cumulative moving average
+                    mom = 1.0 / float(cfg.num_batches_tracked.item())
+                be.bn_update_running(cfg.running_mean, cfg.running_var, mean, invstd, cnt, mom, cfg.eps)
+        else:
+            mean = cfg.running_mean.float()
+            invstd = torch.rsqrt(cfg.running_var.float() + cfg.eps)
+        g32 = gamma.float() if gamma is not None else torch.ones(c, device=x.device)
+        b32 = beta.float() if beta is not None else torch.zeros(c, device=x.device)
+        z = be.bn_apply_act(x, mean, invstd, g32, b32, residual, relu)
+        ctx.save_for_backward(x, z if relu else None, mean, invstd, g32, count_t)
+        ctx.cfg = (be, cfg, relu, world, count, residual is not None,
+                   None if gamma is None else gamma.dtype, None if beta is None else beta.dtype)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, z, mean, invstd, g32, count_t = ctx.saved_tensors
+        be, cfg, relu, world, count, has_res, gdt, bdt = ctx.cfg
+        dz = _cl(dz)
+        sums = be.bn_bwd_reduce(dz, z, x, mean, invstd, relu)  # local [2, C]
+        dgamma = sums[1].to(gdt) if (gdt is not None and ctx.needs_input_grad[1]) else None
+        dbeta = sums[0].to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
+        if cfg.training:
+            gsums, cnt = sums, count
+            if world > 1:
+                # the affine grads above stay local (DDP averages them); the sums that
+                # feed grad_input must be global
+                gsums = sums.clone()
+                tdist.all_reduce(gsums, group=cfg.group)
+                cnt = count_t
+        else:
+            # eval-mode BN: statistics are constants, no reduction terms
+            gsums, cnt = torch.zeros_like(sums), 1.0
+        dx, dres = be.bn_bwd_elemt(dz, z, x, mean, invstd, g32, gsums, cnt, relu,
+                                   has_res and ctx.needs_input_grad[3])
+        if not ctx.needs_input_grad[0]:
+            dx = None
+        return dx, dgamma, dbeta, dres, None, None, None
+
+
+def bn_act(x, gamma, beta, cfg: BNConfig, residual=None, relu: bool = False, stats=None):
+    return _BNActFn.apply(x, gamma, beta, residual, stats, cfg, bool(relu))
+
+
+# -------------------------------------------------------------------- pools
+class _MaxPool3x3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        be = backend_for(x)
+        x = _cl(x)
+        if be is not reference and be.bn_unsupported_reason(x) is not None:
+            _note_fallback("maxpool", "dtype/layout")
+            be = reference
+        y = be.maxpool3x3s2_fwd(x)
+        ctx.save_for_backward(x, y)
+        ctx.be = be
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        return ctx.be.maxpool3x3s2_bwd(_cl(dy), x, y)
+
+
+def maxpool3x3s2(x):
+    return _MaxPool3x3s2Fn.apply(x)
+
+
+class _GlobalAvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        be = backend_for(x)
+        x = _cl(x)
+        if be is not reference and be.bn_unsupported_reason(x) is not None:
+            _note_fallback("avgpool", "dtype/layout")
+            be = reference
+        ctx.be, ctx.shape = be, tuple(x.shape)
+        return be.global_avgpool_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ctx.be.global_avgpool_bwd(dy.contiguous(), ctx.shape)
+
+
+def global_avgpool(x):
+    """``[B,C,H,W] -> [B,C]`` (adaptive avg-pool to 1x1 + flatten)."""
+    return _GlobalAvgPoolFn.apply(x)
+
+
+# --------------------------------------------------------------------- loss
+class _SoftmaxCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        be = backend_for(logits)
+        loss, dlogits = be.softmax_ce_fwd_bwd(logits.contiguous(), labels.contiguous())
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * dloss.to(dlogits.dtype), None
+
+
+def softmax_cross_entropy(logits, labels):
+    """Mean-reduced CE; forward already produces ``(softmax - onehot)/B`` (N11)."""
+    return _SoftmaxCEFn.apply(logits, labels)
+
+
+# ------------------------------------------------------------------ helpers
+def conv_bn_act(x, conv, bn, relu: bool = True, residual=None):
+    """``act(bn(conv(x)) [+ residual])`` through the fused nodes.
+
+    ``conv``/``bn`` are modules (parameter containers); bias-free square convs
+    with dilation 1 and groups 1 take the fused path, anything else falls back
+    to the module's own forward.
+    """
+    from .modules import BatchNorm2d, Conv2d  # local: avoid cycle
+
+    fusable = (
+        isinstance(conv, Conv2d) and isinstance(bn, BatchNorm2d) and conv.bias is None and conv.groups == 1
+        and conv.dilation == (1, 1) and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
+        and conv.kernel_size[0] == conv.kernel_size[1] and isinstance(conv.padding, tuple)
+    )
+    if not fusable:
+        y = bn(conv(x))
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
+    want_stats = bn.training or not bn.track_running_stats
+    y, stats = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats)
+    return bn(y, residual=residual, relu=relu, stats=stats)

@@ -1,0 +1,207 @@
+"""Pure-PyTorch oracles for every native op (same signatures as ``ops.native``).
+
+These run anywhere (CPU, any layout, any dtype) and are (a) the numerics
+oracle the GPU tests compare the HIP kernels against and (b) the compute path
+of the CPU/gloo plumbing configuration.  They are never the shipped GPU path.
+
+Conventions shared with the native ops: image tensors are logical ``[B,C,H,W]``
+(native: channels_last memory = NHWC, bf16); per-channel vectors are fp32.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------- conv ----
+def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False):
+    y = F.conv2d(x, w.to(x.dtype), None, stride, padding)
+    if want_stats:
+        yf = y.float()
+        stats = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))], 0)  # [2, C]
+        return y, stats
+    return y, None
+
+
+def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int):
+    return torch.ops.aten.convolution_backward(
+        dy, torch.empty(x_shape, dtype=dy.dtype, device=dy.device).expand(x_shape), w.to(dy.dtype), None,
+        [stride, stride], [padding, padding], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+
+
+def conv2d_wgrad(dy, x, w_shape, stride: int, padding: int):
+    gw = torch.ops.aten.convolution_backward(
+        dy, x, torch.empty(w_shape, dtype=x.dtype, device=x.device), None,
+        [stride, stride], [padding, padding], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    return gw.float()
+
+
+# ------------------------------------------------------------ batchnorm ----
+def bn_stats(x):
+    """Per-channel ``[sum, sum_sq]`` in fp32, shape ``[2, C]``."""
+    xf = x.float()
+    return torch.stack([xf.sum((0, 2, 3)), (xf * xf).sum((0, 2, 3))], 0)
+
+
+def bn_finalize(stats, count, eps: float):
+    """``[2,C]`` sums + element count -> (mean, invstd) with biased variance."""
+    mean = stats[0] / count
+    var = (stats[1] / count - mean * mean).clamp_min_(0.0)
+    return mean, torch.rsqrt(var + eps)
+
+
+def bn_update_running(running_mean, running_var, mean, invstd, count, momentum: float, eps: float):
+    """In-place running-stat update with the unbiased variance (torch semantics)."""
+    var = 1.0 / (invstd * invstd) - eps
+    unbiased = var * (count / max(count - 1.0, 1.0))
+    running_mean.mul_(1.0 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+    running_var.mul_(1.0 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
+
+
+def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False):
+    """``z = act((x-mean)*invstd*gamma + beta [+ residual])`` in the input dtype."""
+    a = (invstd * gamma).view(1, -1, 1, 1)
+    b = (beta - mean * invstd * gamma).view(1, -1, 1, 1)
+    z = x.float() * a + b
+    if residual is not None:
+        z = z + residual.float()
+    if relu:
+        z = z.clamp_min_(0.0)
+    return z.to(x.dtype)
+
+
+def bn_bwd_reduce(dz, z, x, mean, invstd, relu: bool):
+    """-> ``[2, C]``: ``sum(dzm)``, ``sum(dzm * xhat)`` with ``dzm = dz * (z > 0)``."""
+    g = dz.float()
+    if relu:
+        g = g * (z > 0)
+    xhat = (x.float() - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    return torch.stack([g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))], 0)
+
+
+def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sums, count, relu: bool, want_dres: bool):
+    """-> ``(dx, dres)``; ``sums`` are the (globally reduced) outputs of
+    ``bn_bwd_reduce`` and ``count`` the global element count per channel."""
+    g = dz.float()
+    if relu:
+        g = g * (z > 0)
+    v = lambda t: t.view(1, -1, 1, 1)  # noqa: E731
+    xhat = (x.float() - v(mean)) * v(invstd)
+    dx = v(gamma * invstd) * (g - v(sums[0] / count) - xhat * v(sums[1] / count))
+    dres = g.to(dz.dtype) if want_dres else None
+    return dx.to(x.dtype), dres
+
+
+# ---------------------------------------------------------------- pools ----
+def maxpool3x3s2_fwd(x):
+    return F.max_pool2d(x, 3, 2, 1)
+
+
+def maxpool3x3s2_bwd(dy, x, y):
+    """Gradient routed to the first max in window scan order (torch semantics)."""
+    with torch.enable_grad():
+        xr = x.detach().float().requires_grad_(True)
+        out = F.max_pool2d(xr, 3, 2, 1)
+        (g,) = torch.autograd.grad(out, xr, dy.float())
+    return g.to(x.dtype)
+
+
+def global_avgpool_fwd(x):
+    return x.float().mean((2, 3)).to(x.dtype)
+
+
+def global_avgpool_bwd(dy, x_shape):
+    b, c, h, w = x_shape
+    return (dy.float() / (h * w)).to(dy.dtype).view(b, c, 1, 1).expand(b, c, h, w).contiguous(
+        memory_format=torch.channels_last)
+
+
+# ----------------------------------------------------------------- loss ----
+def softmax_ce_fwd_bwd(logits, labels):
+    """Mean CE loss (fp32 scalar) and ``dlogits = (softmax - onehot)/B`` in the
+    logits dtype, in one pass."""
+    lf = logits.float()
+    lse = torch.logsumexp(lf, 1)
+    picked = lf.gather(1, labels.view(-1, 1)).squeeze(1)
+    loss = (lse - picked).mean()
+    p = torch.softmax(lf, 1)
+    p.scatter_add_(1, labels.view(-1, 1), torch.full_like(picked, -1.0).view(-1, 1))
+    return loss, (p / logits.shape[0]).to(logits.dtype)
+
+
+# ---------------------------------------------------------------- linear ---
+def linear_fwd(x, w, bias):
+    return F.linear(x, w.to(x.dtype), None if bias is None else bias.to(x.dtype))
+
+
+def linear_bwd(dy, x, w):
+    dx = dy @ w.to(dy.dtype)
+    dw = (dy.float().t() @ x.float())
+    db = dy.float().sum(0)
+    return dx, dw, db
+
+
+# ------------------------------------------------------------ optimizers ---
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, adamw: bool, grad_scale: float = 1.0,
+              p_lp=None):
+    g = g.float() * grad_scale
+    if weight_decay != 0.0:
+        if adamw:
+            p.mul_(1.0 - lr * weight_decay)
+        else:
+            g = g + weight_decay * p
+    m.mul_(beta1).add_(g, alpha=1.0 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+    if p_lp is not None:
+        p_lp.copy_(p)
+
+
+def sgd_step(p, g, buf, lr, momentum, dampening, weight_decay, nesterov: bool, first: bool, grad_scale: float = 1.0,
+             p_lp=None):
+    g = g.float() * grad_scale
+    if weight_decay != 0.0:
+        g = g + weight_decay * p
+    if momentum != 0.0:
+        if first:
+            buf.copy_(g)
+        else:
+            buf.mul_(momentum).add_(g, alpha=1.0 - dampening)
+        g = g + momentum * buf if nesterov else buf
+    p.add_(g, alpha=-lr)
+    if p_lp is not None:
+        p_lp.copy_(p)
+
+
+# ------------------------------------------------------- flatten / cast ----
+def flatten_scaled(tensors, flat, offsets, scale: float):
+    """``flat[off_i : off_i+n_i] = tensors[i].flatten() * scale`` (dtype of ``flat``)."""
+    for t, off in zip(tensors, offsets):
+        flat[off: off + t.numel()].copy_((t.reshape(-1).float() * scale))
+
+
+def unflatten(flat, tensors, offsets):
+    for t, off in zip(tensors, offsets):
+        t.copy_(flat[off: off + t.numel()].view_as(t))
+
+
+def nchw_to_nhwc_lowp(x, dtype=torch.bfloat16, scale: float = 1.0):
+    """fp32/uint8 NCHW (or NHWC uint8 when ``x.dim()==4 and x.dtype==uint8 and last dim<=4``)
+    -> channels_last ``dtype`` with an optional scale (1/255 for uint8)."""
+    if x.dtype == torch.uint8 and x.shape[-1] <= 4:  # NHWC uint8 block from the loader
+        x = x.permute(0, 3, 1, 2)
+    return (x.float() * scale).to(dtype).contiguous(memory_format=torch.channels_last)
+
+
+def flatten_scaled_views(grads, views, scale: float):
+    """``views[i] <- grads[i] * scale`` (cast to the view dtype).  ``views[i]`` has the
+    gradient's logical shape; aliasing (``views[i] is grads[i]``'s memory) is allowed."""
+    for g, v in zip(grads, views):
+        if g.data_ptr() == v.data_ptr() and g.stride() == v.stride():
+            if scale != 1.0:
+                v.mul_(scale)
+        else:
+            v.copy_(g.float() * scale if scale != 1.0 else g)
