@@ -1,0 +1,135 @@
+"""Headline benchmark: ResNet-50 bf16 DDP training throughput on MI355X.
+
+    python bench.py --gpus 1 --steps 30 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): whole-job images/sec of ResNet-50 (v1.5, 1000 classes,
+random init) training in bf16 with DDP on synthetic ImageNet-shaped data
+(3x224x224), one process per GPU over RCCL, weak scaling (fixed per-GPU batch).
+Every timed step is a full training iteration: input cast/layout, forward,
+fused softmax-CE, backward with bucketed gradient all-reduce, fused SGD step.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+# Published comparison points recorded in BASELINE.md (NVIDIA DLE ResNet-50 v1.5, DGX A100, AMP):
+# 1 GPU ~2470 img/s, 8 GPUs ~16600 img/s. Intermediate N: linear interpolation of per-GPU throughput.
+_BASE_1, _BASE_8 = 2470.0, 16600.0
+
+
+def baseline_for(n_gpus: int) -> float:
+    per1, per8 = _BASE_1, _BASE_8 / 8.0
+    per = per1 + (per8 - per1) * (min(max(n_gpus, 1), 8) - 1) / 7.0
+    return per * n_gpus
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch_size", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--model", default="resnet50")
+    ap.add_argument("--image_size", type=int, default=224)
+    ap.add_argument("--num_classes", type=int, default=1000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam", "adamw"])
+    ap.add_argument("--sync_bn", action="store_true")
+    ap.add_argument("--bucket_cap_mb", type=float, default=None)
+    ap.add_argument("--backend", default=None)
+    ap.add_argument("--reducer", default=None)
+    args = ap.parse_args(argv)
+
+    from pytorch_distributed_training_amd import dist as pdist
+    from pytorch_distributed_training_amd import native_available
+    from pytorch_distributed_training_amd.data import SyntheticDeviceLoader
+    from pytorch_distributed_training_amd.engine import Engine, EngineConfig
+    from pytorch_distributed_training_amd.nn import functional as pF
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus and world_env > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
+    env = pdist.init_process_group(backend=args.backend, local_rank=int(os.environ.get("LOCAL_RANK", "0")))
+    on_gpu = env.device.type == "cuda"
+    if on_gpu and not native_available():
+        raise SystemExit("the native extension is not built: run `python __graft_entry__.py build`")
+
+    engine = Engine(EngineConfig(
+        model=args.model, num_classes=args.num_classes, dtype=args.dtype, optimizer=args.optimizer,
+        lr=0.1 if args.optimizer == "sgd" else 1e-3, momentum=0.9, weight_decay=1e-4 if args.optimizer == "sgd" else 0.0,
+        sync_bn=args.sync_bn, bucket_cap_mb=args.bucket_cap_mb, reducer=args.reducer, seed=0,
+        image_size=args.image_size))
+    loader = SyntheticDeviceLoader(args.batch_size, (3, args.image_size, args.image_size), args.num_classes,
+                                   device=env.device, dtype=torch.float32, ring=2, seed=env.rank)
+    it = iter(loader)
+
+    def sync():
+        pdist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = engine.train_step(*next(it))
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = engine.train_step(*next(it))
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=env.device if on_gpu else "cpu")
+    if env.world_size > 1:
+        import torch.distributed as tdist
+
+        if on_gpu:
+            t = t.float()
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    final_loss = float(loss.item()) if loss is not None else float("nan")
+
+    if env.rank == 0:
+        n = env.world_size
+        global_batch = args.batch_size * n
+        value = global_batch * args.steps / elapsed
+        base = baseline_for(n)
+        out = {
+            "metric": "images/sec (whole job) ResNet-50 bf16 DDP training" if args.model == "resnet50"
+            else f"images/sec (whole job) {args.model} DDP training",
+            "value": round(value, 2),
+            "unit": "images/sec",
+            "n_gpus": n,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": round(value / base, 4) if args.model == "resnet50" else None,
+            "dtype": args.dtype if on_gpu else "fp32",
+            "data": "synthetic",
+            "config": {
+                "model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch_size,
+                "image_size": args.image_size, "seq_len": None, "parallelism": f"dp{n}",
+                "optimizer": args.optimizer, "sync_bn": bool(args.sync_bn), "reducer": engine.net.reducer_kind,
+                "backend": env.backend, "baseline_images_per_sec": round(base, 1),
+                "library_fallbacks": dict(pF.fallback_counts), "final_loss": final_loss,
+            },
+        }
+        print(json.dumps(out), flush=True)
+    pdist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,325 @@
+"""GPU numerics + timing sweep of every native kernel against the PyTorch oracles.
+
+Runs every case even when an earlier one fails (a gpurun round trip is
+expensive), prints one line per case and a JSON summary under gpurun_out/.
+
+    python bench/kernel_check.py [--quick] [--time] [--only conv,bn,...]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import traceback
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from pytorch_distributed_training_amd.ops import native, reference  # noqa: E402
+
+DEV = "cuda"
+RESULTS = []
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    denom = b.abs().max().clamp_min(1e-6)
+    return float((a - b).abs().max() / denom)
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def record(name, ok, err, extra=None):
+    r = {"case": name, "ok": bool(ok), "err": err}
+    if extra:
+        r.update(extra)
+    RESULTS.append(r)
+    print(("PASS " if ok else "FAIL ") + name + f"  err={err:.3e}" + (f"  {extra}" if extra else ""), flush=True)
+
+
+def run_case(name, fn):
+    try:
+        fn()
+    except Exception as e:  # keep going: one call must report everything
+        traceback.print_exc()
+        record(name, False, float("nan"), {"exception": repr(e)[:300]})
+    torch.cuda.synchronize()
+
+
+def nhwc(*shape, scale=1.0):
+    return (torch.randn(*shape, device=DEV) * scale).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+
+# ------------------------------------------------------------------------------ conv
+def conv_cases(quick):
+    cases = [
+        # B, Cin, H, W, Cout, k, stride, pad
+        (2, 64, 8, 8, 64, 1, 1, 0),
+        (2, 64, 9, 7, 128, 3, 1, 1),
+        (3, 128, 10, 10, 64, 3, 2, 1),
+        (2, 256, 8, 8, 512, 1, 2, 0),
+        (2, 64, 13, 13, 64, 3, 1, 1),
+        (4, 128, 14, 14, 256, 1, 1, 0),
+        (2, 512, 7, 7, 512, 3, 1, 1),
+    ]
+    if not quick:
+        cases += [
+            (32, 64, 56, 56, 64, 3, 1, 1),
+            (32, 256, 56, 56, 128, 1, 1, 0),
+            (32, 128, 56, 56, 128, 3, 2, 1),
+            (32, 1024, 14, 14, 2048, 1, 2, 0),
+            (32, 512, 7, 7, 2048, 1, 1, 0),
+        ]
+    return cases
+
+
+def check_conv(args, time_it):
+    B, C, H, W, N, k, s, p = args
+    tag = f"B{B} {C}->{N} {H}x{W} k{k} s{s} p{p}"
+    x = nhwc(B, C, H, W)
+    w = (torch.randn(N, C, k, k, device=DEV) * (1.0 / (C * k * k) ** 0.5)).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+
+    def fwd():
+        y, st = native.conv2d_fwd(x, w, s, p, True)
+        yr, _ = reference.conv2d_fwd(x.float(), w.float(), s, p, False)
+        e = rel_err(y, yr)
+        str_ = reference.bn_stats(y)
+        es = rel_err(st, str_)
+        extra = {"stats_err": es}
+        if time_it:
+            us = timeit(lambda: native.conv2d_fwd(x, w, s, p, True))
+            us_lib = timeit(lambda: torch.nn.functional.conv2d(x, w, None, s, p))
+            fl = 2.0 * y.numel() * C * k * k
+            extra.update({"us": round(us, 1), "us_miopen": round(us_lib, 1), "TF": round(fl / us / 1e6, 1)})
+        record(f"conv_fwd   {tag}", e < 2e-2 and es < 2e-2, e, extra)
+
+    def dgrad():
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        dy = nhwc(B, N, Ho, Wo)
+        dx = native.conv2d_dgrad(dy, w, (B, C, H, W), s, p)
+        dxr = reference.conv2d_dgrad(dy.float(), w.float(), (B, C, H, W), s, p)
+        e = rel_err(dx, dxr)
+        extra = {}
+        if time_it:
+            us = timeit(lambda: native.conv2d_dgrad(dy, w, (B, C, H, W), s, p))
+            us_lib = timeit(lambda: reference.conv2d_dgrad(dy, w, (B, C, H, W), s, p))
+            fl = 2.0 * dy.numel() * C * k * k
+            extra.update({"us": round(us, 1), "us_miopen": round(us_lib, 1), "TF": round(fl / us / 1e6, 1)})
+        record(f"conv_dgrad {tag}", e < 2e-2, e, extra)
+
+    def wgrad():
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        dy = nhwc(B, N, Ho, Wo)
+        dw = native.conv2d_wgrad(dy, x, (N, C, k, k), s, p)
+        dwr = reference.conv2d_wgrad(dy.float(), x.float(), (N, C, k, k), s, p)
+        e = rel_err(dw, dwr)
+        extra = {}
+        if time_it:
+            us = timeit(lambda: native.conv2d_wgrad(dy, x, (N, C, k, k), s, p))
+            us_lib = timeit(lambda: reference.conv2d_wgrad(dy, x, (N, C, k, k), s, p))
+            fl = 2.0 * dy.numel() * C * k * k
+            extra.update({"us": round(us, 1), "us_miopen": round(us_lib, 1), "TF": round(fl / us / 1e6, 1)})
+        record(f"conv_wgrad {tag}", e < 2e-2, e, extra)
+
+    run_case(f"conv_fwd   {tag}", fwd)
+    run_case(f"conv_dgrad {tag}", dgrad)
+    run_case(f"conv_wgrad {tag}", wgrad)
+
+
+# -------------------------------------------------------------------------------- bn
+def check_bn(B, C, H, W, time_it):
+    tag = f"B{B} C{C} {H}x{W}"
+    x = nhwc(B, C, H, W) * 2 + 0.5
+    x = x.contiguous(memory_format=torch.channels_last)
+    res = nhwc(B, C, H, W)
+    gamma = torch.rand(C, device=DEV) + 0.5
+    beta = torch.randn(C, device=DEV) * 0.1
+    count = float(B * H * W)
+
+    def stats():
+        st = native.bn_stats(x)
+        e = rel_err(st, reference.bn_stats(x))
+        extra = {"us": round(timeit(lambda: native.bn_stats(x)), 1)} if time_it else None
+        record(f"bn_stats   {tag}", e < 1e-3, e, extra)
+
+    def fin_apply():
+        st = reference.bn_stats(x)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        rm2, rv2 = rm.clone(), rv.clone()
+        mean, invstd = native.bn_finalize(st, count, 1e-5, rm, rv, 0.1)
+        mr, ir = reference.bn_finalize(st, count, 1e-5, rm2, rv2, 0.1)
+        e = max(rel_err(mean, mr), rel_err(invstd, ir), rel_err(rm, rm2), rel_err(rv, rv2))
+        record(f"bn_finalize {tag}", e < 1e-4, e)
+        for relu, use_res in ((True, True), (True, False), (False, False), (False, True)):
+            z = native.bn_apply_act(x, mr, ir, gamma, beta, res if use_res else None, relu)
+            zr = reference.bn_apply_act(x, mr, ir, gamma, beta, res if use_res else None, relu)
+            e = rel_err(z, zr)
+            extra = None
+            if time_it and relu and use_res:
+                us = timeit(lambda: native.bn_apply_act(x, mr, ir, gamma, beta, res, True))
+                extra = {"us": round(us, 1), "GBps": round(3 * x.numel() * 2 / us / 1e3, 1)}
+            record(f"bn_apply r{int(relu)} res{int(use_res)} {tag}", e < 1e-2, e, extra)
+
+    def bwd():
+        st = reference.bn_stats(x)
+        mean, invstd = reference.bn_finalize(st, count, 1e-5)
+        z = reference.bn_apply_act(x, mean, invstd, gamma, beta, res, True)
+        dz = nhwc(B, C, H, W)
+        for relu in (True, False):
+            sums = native.bn_bwd_reduce(dz, z, x, mean, invstd, relu)
+            sr = reference.bn_bwd_reduce(dz, z, x, mean, invstd, relu)
+            e = rel_err(sums, sr)
+            extra = {"us": round(timeit(lambda: native.bn_bwd_reduce(dz, z, x, mean, invstd, relu)), 1)} if time_it else None
+            record(f"bn_bwd_reduce r{int(relu)} {tag}", e < 2e-3, e, extra)
+            for dres in (True, False):
+                dx, dr = native.bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sr, count, relu, dres)
+                dxr, drr = reference.bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sr, count, relu, dres)
+                e = rel_err(dx, dxr)
+                if dres:
+                    e = max(e, rel_err(dr, drr))
+                record(f"bn_bwd_elemt r{int(relu)} dres{int(dres)} {tag}", e < 1e-2, e)
+
+    run_case(f"bn_stats {tag}", stats)
+    run_case(f"bn_finalize/apply {tag}", fin_apply)
+    run_case(f"bn_bwd {tag}", bwd)
+
+
+# ----------------------------------------------------------------------------- others
+def check_pool():
+    for (B, C, H, W) in ((2, 64, 16, 16), (3, 64, 15, 17), (4, 64, 112, 112)):
+        def mp():
+            x = nhwc(B, C, H, W).relu_().contiguous(memory_format=torch.channels_last)
+            y, arg = native.maxpool3x3s2_fwd(x)
+            yr, _ = reference.maxpool3x3s2_fwd(x)
+            e = rel_err(y, yr)
+            dy = nhwc(*y.shape)
+            dx = native.maxpool3x3s2_bwd(dy, x, y, arg)
+            dxr = reference.maxpool3x3s2_bwd(dy, x, yr)
+            record(f"maxpool B{B} C{C} {H}x{W}", e == 0 and rel_err(dx, dxr) < 1e-2, max(e, rel_err(dx, dxr)))
+        run_case("maxpool", mp)
+    for (B, C, H, W) in ((4, 2048, 7, 7), (3, 512, 4, 4)):
+        def ap():
+            x = nhwc(B, C, H, W)
+            y = native.global_avgpool_fwd(x)
+            e = rel_err(y, reference.global_avgpool_fwd(x))
+            dy = torch.randn(B, C, device=DEV).bfloat16()
+            dx = native.global_avgpool_bwd(dy, x.shape)
+            e2 = rel_err(dx, reference.global_avgpool_bwd(dy, x.shape))
+            record(f"avgpool B{B} C{C} {H}x{W}", max(e, e2) < 1e-2, max(e, e2))
+        run_case("avgpool", ap)
+
+
+def check_loss(time_it):
+    for (B, N, dt) in ((256, 1000, torch.bfloat16), (33, 1000, torch.float32), (7, 10, torch.bfloat16), (5, 3001, torch.float32)):
+        def ce():
+            logits = (torch.randn(B, N, device=DEV) * 3).to(dt)
+            labels = torch.randint(0, N, (B,), device=DEV)
+            loss, dl = native.softmax_ce_fwd_bwd(logits, labels)
+            lr, dlr = reference.softmax_ce_fwd_bwd(logits, labels)
+            e = max(abs(float(loss) - float(lr)) / max(abs(float(lr)), 1e-6), rel_err(dl, dlr))
+            extra = {"us": round(timeit(lambda: native.softmax_ce_fwd_bwd(logits, labels)), 1)} if time_it else None
+            record(f"softmax_ce B{B} N{N} {dt}", e < 1e-2, e, extra)
+        run_case("softmax_ce", ce)
+
+
+def check_optim(time_it):
+    def run(kind):
+        g = torch.Generator(device="cpu").manual_seed(0)
+        shapes = [(64, 3, 7, 7), (64,), (256, 64, 1, 1), (1000, 2048), (1000,), (513,), (128, 128, 3, 3)]
+        ps = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+        gs = [torch.randn(s, generator=g).to(DEV) * 0.1 for s in shapes]
+        lps = [p.to(torch.bfloat16) for p in ps]
+        ps_r = [p.clone() for p in ps]
+        lps_r = [p.clone() for p in lps]
+        if kind == "adam":
+            ms, vs = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+            ms_r, vs_r = [m.clone() for m in ms], [v.clone() for v in vs]
+            for step in (1, 2, 3):
+                native.multi_adam(ps, gs, ms, vs, lps, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, True)
+                for p, gg, m, v, lp in zip(ps_r, gs, ms_r, vs_r, lps_r):
+                    reference.adam_step(p, gg, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, float(step), True, 1.0, lp)
+        else:
+            bufs = [torch.zeros_like(p) for p in ps]
+            bufs_r = [b.clone() for b in bufs]
+            for step in (1, 2, 3):
+                native.multi_sgd(ps, gs, bufs, lps, 0.1, 0.9, 0.0, 1e-4, False, step == 1)
+                for p, gg, b, lp in zip(ps_r, gs, bufs_r, lps_r):
+                    reference.sgd_step(p, gg, b, 0.1, 0.9, 0.0, 1e-4, False, step == 1, 1.0, lp)
+        e = max(max(rel_err(a, b) for a, b in zip(ps, ps_r)), max(rel_err(a, b) for a, b in zip(lps, lps_r)))
+        record(f"multi_{kind}", e < 1e-5, e)
+    run_case("multi_adam", lambda: run("adam"))
+    run_case("multi_sgd", lambda: run("sgd"))
+
+    def flat():
+        srcs = [torch.randn(n, device=DEV) for n in (5, 4096, 4097, 100000, 64)]
+        for dt in (torch.float32, torch.bfloat16):
+            dsts = [torch.zeros(n, device=DEV, dtype=dt) for n in (5, 4096, 4097, 100000, 64)]
+            native.flatten_scaled_views(srcs, dsts, 0.125)
+            e = max(rel_err(d, s * 0.125) for s, d in zip(srcs, dsts))
+            record(f"multi_flatten -> {dt}", e < 1e-2, e)
+    run_case("multi_flatten", flat)
+
+    def cast():
+        x = torch.rand(5, 3, 32, 32, device=DEV)
+        y = native.nchw_to_nhwc_lowp(x)
+        yr = reference.nchw_to_nhwc_lowp(x)
+        ok = y.is_contiguous(memory_format=torch.channels_last)
+        record("to_nhwc_bf16 f32 32x32", ok and rel_err(y, yr) == 0, rel_err(y, yr))
+        x = torch.rand(3, 3, 224, 224, device=DEV)
+        y = native.nchw_to_nhwc_lowp(x)
+        record("to_nhwc_bf16 f32 224x224", rel_err(y, reference.nchw_to_nhwc_lowp(x)) == 0, rel_err(y, reference.nchw_to_nhwc_lowp(x)))
+        u = torch.randint(0, 256, (4, 32, 32, 3), device=DEV, dtype=torch.uint8)
+        y = native.nchw_to_nhwc_lowp(u, torch.bfloat16, 1 / 255.0)
+        record("to_nhwc_bf16 u8", rel_err(y, reference.nchw_to_nhwc_lowp(u, torch.bfloat16, 1 / 255.0)) < 1e-2,
+               rel_err(y, reference.nchw_to_nhwc_lowp(u, torch.bfloat16, 1 / 255.0)))
+    run_case("cast", cast)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--time", action="store_true")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--out", default="gpurun_out/kernel_check.json")
+    a = ap.parse_args()
+    only = set(a.only.split(",")) if a.only else None
+    torch.manual_seed(0)
+    t0 = time.time()
+    if only is None or "elt" in only:
+        check_optim(a.time)
+        check_loss(a.time)
+        check_pool()
+    if only is None or "bn" in only:
+        shapes = [(4, 64, 8, 8), (3, 256, 7, 5), (2, 2048, 3, 3), (5, 128, 9, 9)]
+        if not a.quick:
+            shapes += [(64, 64, 56, 56), (64, 256, 56, 56), (64, 2048, 7, 7)]
+        for s in shapes:
+            check_bn(*s, a.time)
+    if only is None or "conv" in only:
+        for c in conv_cases(a.quick):
+            check_conv(c, a.time)
+    n_fail = sum(1 for r in RESULTS if not r["ok"])
+    print(f"\n{len(RESULTS)} cases, {n_fail} failed, {time.time() - t0:.1f}s", flush=True)
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+    with open(a.out, "w") as f:
+        json.dump({"results": RESULTS, "failed": n_fail}, f, indent=1)
+    return 1 if n_fail else 0  # 1 = numeric mismatches only (every case ran)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

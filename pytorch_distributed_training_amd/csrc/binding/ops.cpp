@@ -1,0 +1,571 @@
+// Torch bindings of the gfx950 kernels: validate operands on the host (a faulting kernel can
+// take the whole node down, so every shape / dtype / layout / size assumption of a kernel is
+// checked here), allocate outputs through the caching allocator, launch on the current stream.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/extension.h>
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+
+#include "../kernels/kernels.h"
+#include "binding.h"
+
+namespace pdt {
+namespace {
+
+using at::Tensor;
+
+hipStream_t cur_stream(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+void check_nhwc_bf16(const Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda(), name, ": expected a GPU tensor");
+    TORCH_CHECK(t.scalar_type() == at::kBFloat16, name, ": expected bf16, got ", t.scalar_type());
+    TORCH_CHECK(t.dim() == 4, name, ": expected 4-D [B,C,H,W]");
+    TORCH_CHECK(t.is_contiguous(at::MemoryFormat::ChannelsLast), name, ": expected channels_last (NHWC) memory");
+    TORCH_CHECK((long)t.numel() * 2 < (1L << 31), name, ": tensor exceeds the 2 GiB buffer-descriptor range");
+    TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, ": data pointer must be 16-B aligned");
+}
+void check_vec_f32(const Tensor& t, long n, const char* name) {
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.is_contiguous() && t.numel() == n, name,
+                ": expected contiguous fp32 GPU tensor with ", n, " elements");
+    TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, ": data pointer must be 16-B aligned");
+}
+bool bn_channels_ok(long C) { return C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0; }
+
+Tensor empty_nhwc(long B, long C, long H, long W, const Tensor& like) {
+    return at::empty({B, C, H, W}, like.options().memory_format(at::MemoryFormat::ChannelsLast));
+}
+
+Tensor reduce_slab(const Tensor& slab, int nparts, long n) {
+    Tensor out = at::empty({n}, slab.options());
+    Tensor tmp;
+    float* tmp_ptr = nullptr;
+    if (nparts > 64) {
+        tmp = at::empty({kReduceChunks, n}, slab.options());
+        tmp_ptr = tmp.data_ptr<float>();
+    }
+    launch_reduce_slab(slab.data_ptr<float>(), nparts, n, (int)n, out.data_ptr<float>(), tmp_ptr, cur_stream(slab));
+    return out;
+}
+
+// ------------------------------------------------------------------------------------- conv
+void check_conv_weight(const Tensor& w, const char* name) {
+    TORCH_CHECK(w.is_cuda() && w.scalar_type() == at::kBFloat16 && w.dim() == 4, name, ": expected 4-D bf16 GPU weight");
+    TORCH_CHECK(w.is_contiguous(at::MemoryFormat::ChannelsLast), name,
+                ": expected channels_last weight (physical [Cout][kh][kw][Cin])");
+    TORCH_CHECK(reinterpret_cast<uintptr_t>(w.data_ptr()) % 16 == 0, name, ": data pointer must be 16-B aligned");
+}
+
+std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, bool want_stats) {
+    check_nhwc_bf16(x, "x");
+    check_conv_weight(w, "w");
+    const long B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+    const long N = w.size(0), KH = w.size(2), KW = w.size(3);
+    TORCH_CHECK(w.size(1) == C, "weight Cin ", w.size(1), " != input C ", C);
+    TORCH_CHECK(C % 64 == 0 && N % 64 == 0, "conv2d_fwd: Cin and Cout must be multiples of 64 (got ", C, ", ", N, ")");
+    TORCH_CHECK(KH * KW <= kMaxTaps && stride >= 1 && pad >= 0 && pad < 64, "unsupported kernel geometry");
+    const long Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    TORCH_CHECK(Ho > 0 && Wo > 0, "empty output");
+    c10::hip::HIPGuard guard(x.device());
+    Tensor y = empty_nhwc(B, N, Ho, Wo, x);
+    TORCH_CHECK((long)y.numel() * 2 < (1L << 31), "output exceeds 2 GiB");
+    ConvGeom g;
+    std::memset(&g, 0, sizeof(g));
+    g.B = B; g.Hin = H; g.Win = W; g.C = C; g.Hout = Ho; g.Wout = Wo; g.N = N;
+    g.nOH = Ho; g.nOW = Wo; g.os = 1; g.ooh = 0; g.oow = 0; g.is = stride;
+    g.ntaps = KH * KW; g.wtaps = KH * KW;
+    for (int r = 0; r < KH; ++r)
+        for (int s = 0; s < KW; ++s) {
+            const int t = r * KW + s;
+            g.dh[t] = (int8_t)(r - pad); g.dw[t] = (int8_t)(s - pad); g.wslot[t] = (int8_t)t;
+        }
+    Tensor stats;
+    float* slab_ptr = nullptr;
+    Tensor slab;
+    int m_tiles = conv_igemm_m_tiles(g, nullptr);
+    if (want_stats) {
+        slab = at::empty({m_tiles, 2 * N}, x.options().dtype(at::kFloat));
+        slab_ptr = slab.data_ptr<float>();
+    }
+    launch_conv_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), g, slab_ptr, cur_stream(x));
+    if (want_stats) stats = reduce_slab(slab, m_tiles, 2 * N).view({2, N});
+    return {y, stats};
+}
+
+// wt: [Cin][KH*KW][Cout] bf16 contiguous (transpose_weight(w))
+Tensor conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_shape, int64_t KH, int64_t KW,
+                    int64_t stride, int64_t pad) {
+    check_nhwc_bf16(dy, "dy");
+    TORCH_CHECK(wt.is_cuda() && wt.scalar_type() == at::kBFloat16 && wt.dim() == 3 && wt.is_contiguous(),
+                "wt: expected contiguous bf16 [Cin][taps][Cout]");
+    TORCH_CHECK(x_shape.size() == 4, "x_shape must be [B,C,H,W]");
+    const long B = x_shape[0], C = x_shape[1], H = x_shape[2], W = x_shape[3];
+    const long N = dy.size(1), Ho = dy.size(2), Wo = dy.size(3);
+    TORCH_CHECK(dy.size(0) == B && wt.size(0) == C && wt.size(1) == KH * KW && wt.size(2) == N, "dgrad shape mismatch");
+    TORCH_CHECK(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1, "dgrad geometry mismatch");
+    TORCH_CHECK(C % 64 == 0 && N % 64 == 0, "conv2d_dgrad: channels must be multiples of 64");
+    TORCH_CHECK(stride == 1 || stride == 2, "conv2d_dgrad: stride must be 1 or 2");
+    TORCH_CHECK(KH * KW <= kMaxTaps && pad < 64, "unsupported kernel geometry");
+    c10::hip::HIPGuard guard(dy.device());
+    hipStream_t s = cur_stream(dy);
+
+    auto base_geom = [&]() {
+        ConvGeom g;
+        std::memset(&g, 0, sizeof(g));
+        g.B = B; g.Hin = Ho; g.Win = Wo; g.C = N;      // gather from dY, reduce over Cout
+        g.Hout = H; g.Wout = W; g.N = C;               // write dX, produce Cin
+        g.is = 1; g.wtaps = KH * KW;
+        return g;
+    };
+    if (stride == 1) {
+        Tensor dx = empty_nhwc(B, C, H, W, dy);
+        TORCH_CHECK((long)dx.numel() * 2 < (1L << 31), "dx exceeds 2 GiB");
+        ConvGeom g = base_geom();
+        g.nOH = H; g.nOW = W; g.os = 1;
+        g.ntaps = KH * KW;
+        for (int r = 0; r < KH; ++r)
+            for (int q = 0; q < KW; ++q) {
+                const int t = r * KW + q;
+                g.dh[t] = (int8_t)(pad - r); g.dw[t] = (int8_t)(pad - q); g.wslot[t] = (int8_t)t;
+            }
+        launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, nullptr, s);
+        return dx;
+    }
+    // stride 2: one launch per output parity class; a class without taps stays zero
+    bool need_zero = false;
+    std::vector<ConvGeom> launches;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            ConvGeom g = base_geom();
+            g.os = 2; g.ooh = ph; g.oow = pw;
+            g.nOH = (H - ph + 1) / 2; g.nOW = (W - pw + 1) / 2;
+            int nt = 0;
+            for (int r = 0; r < KH; ++r) {
+                if (((ph + pad - r) % 2) != 0) continue;
+                for (int q = 0; q < KW; ++q) {
+                    if (((pw + pad - q) % 2) != 0) continue;
+                    g.dh[nt] = (int8_t)((ph + pad - r) / 2);
+                    g.dw[nt] = (int8_t)((pw + pad - q) / 2);
+                    g.wslot[nt] = (int8_t)(r * KW + q);
+                    ++nt;
+                }
+            }
+            g.ntaps = nt;
+            if (g.nOH <= 0 || g.nOW <= 0) continue;
+            if (nt == 0) { need_zero = true; continue; }
+            launches.push_back(g);
+        }
+    Tensor dx = need_zero ? at::zeros({B, C, H, W}, dy.options().memory_format(at::MemoryFormat::ChannelsLast))
+                          : empty_nhwc(B, C, H, W, dy);
+    TORCH_CHECK((long)dx.numel() * 2 < (1L << 31), "dx exceeds 2 GiB");
+    for (const auto& g : launches) launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, nullptr, s);
+    return dx;
+}
+
+Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, int64_t stride, int64_t pad) {
+    check_nhwc_bf16(dy, "dy");
+    check_nhwc_bf16(x, "x");
+    const long B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+    const long N = dy.size(1), Ho = dy.size(2), Wo = dy.size(3);
+    TORCH_CHECK(dy.size(0) == B, "batch mismatch");
+    TORCH_CHECK(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1, "wgrad geometry mismatch");
+    TORCH_CHECK(C % 64 == 0 && N % 64 == 0, "conv2d_wgrad: channels must be multiples of 64");
+    TORCH_CHECK((long)B * Ho * Wo < (1L << 31), "too many output pixels");
+    c10::hip::HIPGuard guard(x.device());
+    WgradGeom g{(int)B, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, (int)N, (int)KH, (int)KW, (int)stride, (int)pad, 1};
+    g.splits = conv_wgrad_splits(g);
+    const long wsize = N * KH * KW * C;
+    Tensor slab = at::empty({g.splits, wsize}, x.options().dtype(at::kFloat));
+    launch_conv_wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr<float>(), g, cur_stream(x));
+    Tensor flat = g.splits == 1 ? slab.view({wsize}) : reduce_slab(slab, g.splits, wsize);
+    // physical [N][KH][KW][C] == logical [N,C,KH,KW] in channels_last
+    return flat.view({N, KH, KW, C}).permute({0, 3, 1, 2});
+}
+
+Tensor transpose_weight(const Tensor& w) {
+    check_conv_weight(w, "w");
+    const long N = w.size(0), C = w.size(1), T = w.size(2) * w.size(3);
+    c10::hip::HIPGuard guard(w.device());
+    Tensor wt = at::empty({C, T, N}, w.options().memory_format(at::MemoryFormat::Contiguous));
+    launch_transpose_ntc(w.data_ptr(), wt.data_ptr(), (int)N, (int)T, (int)C, cur_stream(w));
+    return wt;
+}
+
+// --------------------------------------------------------------------------------------- bn
+Tensor bn_stats(const Tensor& x) {
+    check_nhwc_bf16(x, "x");
+    const long C = x.size(1), M = x.numel() / C;
+    TORCH_CHECK(bn_channels_ok(C), "bn: unsupported channel count ", C);
+    c10::hip::HIPGuard guard(x.device());
+    const int parts = bn_parts(M, (int)C);
+    Tensor slab = at::empty({parts, 2 * C}, x.options().dtype(at::kFloat));
+    launch_bn_stats(x.data_ptr(), M, (int)C, slab.data_ptr<float>(), parts, cur_stream(x));
+    return reduce_slab(slab, parts, 2 * C).view({2, C});
+}
+
+std::tuple<Tensor, Tensor> bn_finalize(const Tensor& stats, double count, const c10::optional<Tensor>& count_dev,
+                                       double eps, double momentum, const c10::optional<Tensor>& running_mean,
+                                       const c10::optional<Tensor>& running_var) {
+    TORCH_CHECK(stats.is_cuda() && stats.scalar_type() == at::kFloat && stats.dim() == 2 && stats.size(0) == 2 &&
+                    stats.is_contiguous(),
+                "stats: expected contiguous fp32 [2, C]");
+    const long C = stats.size(1);
+    c10::hip::HIPGuard guard(stats.device());
+    Tensor mean = at::empty({C}, stats.options()), invstd = at::empty({C}, stats.options());
+    float *rm = nullptr, *rv = nullptr;
+    if (running_mean.has_value() && running_mean->defined()) {
+        check_vec_f32(*running_mean, C, "running_mean");
+        check_vec_f32(*running_var, C, "running_var");
+        rm = running_mean->data_ptr<float>();
+        rv = running_var->data_ptr<float>();
+    }
+    const float* cd = nullptr;
+    if (count_dev.has_value() && count_dev->defined()) {
+        TORCH_CHECK(count_dev->is_cuda() && count_dev->scalar_type() == at::kFloat && count_dev->numel() == 1,
+                    "count_dev: expected a 1-element fp32 GPU tensor");
+        cd = count_dev->data_ptr<float>();
+    }
+    launch_bn_finalize(stats.data_ptr<float>(), (int)C, (float)count, cd, (float)eps, (float)momentum, rm, rv,
+                       mean.data_ptr<float>(), invstd.data_ptr<float>(), cur_stream(stats));
+    return {mean, invstd};
+}
+
+Tensor bn_apply_act(const Tensor& x, const Tensor& mean, const Tensor& invstd, const Tensor& gamma, const Tensor& beta,
+                    const c10::optional<Tensor>& residual, bool relu) {
+    check_nhwc_bf16(x, "x");
+    const long C = x.size(1), M = x.numel() / C;
+    TORCH_CHECK(bn_channels_ok(C), "bn: unsupported channel count ", C);
+    check_vec_f32(mean, C, "mean"); check_vec_f32(invstd, C, "invstd");
+    check_vec_f32(gamma, C, "gamma"); check_vec_f32(beta, C, "beta");
+    const void* res = nullptr;
+    if (residual.has_value() && residual->defined()) {
+        check_nhwc_bf16(*residual, "residual");
+        TORCH_CHECK(residual->sizes() == x.sizes(), "residual shape mismatch");
+        res = residual->data_ptr();
+    }
+    c10::hip::HIPGuard guard(x.device());
+    Tensor z = at::empty_like(x);
+    launch_bn_apply(x.data_ptr(), res, z.data_ptr(), M, (int)C, mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                    gamma.data_ptr<float>(), beta.data_ptr<float>(), relu ? 1 : 0, cur_stream(x));
+    return z;
+}
+
+Tensor bn_bwd_reduce(const Tensor& dz, const c10::optional<Tensor>& z, const Tensor& x, const Tensor& mean,
+                     const Tensor& invstd, bool relu) {
+    check_nhwc_bf16(dz, "dz"); check_nhwc_bf16(x, "x");
+    TORCH_CHECK(dz.sizes() == x.sizes(), "dz/x shape mismatch");
+    const long C = x.size(1), M = x.numel() / C;
+    TORCH_CHECK(bn_channels_ok(C), "bn: unsupported channel count ", C);
+    check_vec_f32(mean, C, "mean"); check_vec_f32(invstd, C, "invstd");
+    const void* zp = nullptr;
+    if (relu) {
+        TORCH_CHECK(z.has_value() && z->defined(), "relu=True needs the forward output z");
+        check_nhwc_bf16(*z, "z");
+        TORCH_CHECK(z->sizes() == x.sizes(), "z shape mismatch");
+        zp = z->data_ptr();
+    }
+    c10::hip::HIPGuard guard(x.device());
+    const int parts = bn_parts(M, (int)C);
+    Tensor slab = at::empty({parts, 2 * C}, x.options().dtype(at::kFloat));
+    launch_bn_bwd_reduce(dz.data_ptr(), zp, x.data_ptr(), M, (int)C, mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                         relu ? 1 : 0, slab.data_ptr<float>(), parts, cur_stream(x));
+    return reduce_slab(slab, parts, 2 * C).view({2, C});
+}
+
+std::tuple<Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::optional<Tensor>& z, const Tensor& x,
+                                        const Tensor& mean, const Tensor& invstd, const Tensor& gamma,
+                                        const Tensor& sums, double count, const c10::optional<Tensor>& count_dev,
+                                        bool relu, bool want_dres) {
+    check_nhwc_bf16(dz, "dz"); check_nhwc_bf16(x, "x");
+    TORCH_CHECK(dz.sizes() == x.sizes(), "dz/x shape mismatch");
+    const long C = x.size(1), M = x.numel() / C;
+    TORCH_CHECK(bn_channels_ok(C), "bn: unsupported channel count ", C);
+    check_vec_f32(mean, C, "mean"); check_vec_f32(invstd, C, "invstd"); check_vec_f32(gamma, C, "gamma");
+    check_vec_f32(sums, 2 * C, "sums");
+    const void* zp = nullptr;
+    if (relu) {
+        TORCH_CHECK(z.has_value() && z->defined(), "relu=True needs the forward output z");
+        check_nhwc_bf16(*z, "z");
+        TORCH_CHECK(z->sizes() == x.sizes(), "z shape mismatch");
+        zp = z->data_ptr();
+    }
+    const float* cd = nullptr;
+    if (count_dev.has_value() && count_dev->defined()) {
+        TORCH_CHECK(count_dev->is_cuda() && count_dev->scalar_type() == at::kFloat && count_dev->numel() == 1,
+                    "count_dev: expected a 1-element fp32 GPU tensor");
+        cd = count_dev->data_ptr<float>();
+    }
+    c10::hip::HIPGuard guard(x.device());
+    Tensor dx = at::empty_like(x), dres;
+    void* drp = nullptr;
+    if (want_dres) {
+        dres = at::empty_like(x);
+        drp = dres.data_ptr();
+    }
+    launch_bn_bwd_elemt(dz.data_ptr(), zp, x.data_ptr(), dx.data_ptr(), drp, M, (int)C, mean.data_ptr<float>(),
+                        invstd.data_ptr<float>(), gamma.data_ptr<float>(), sums.data_ptr<float>(), (float)count, cd,
+                        relu ? 1 : 0, cur_stream(x));
+    return {dx, dres};
+}
+
+// ------------------------------------------------------------------------------------ pools
+std::tuple<Tensor, Tensor> maxpool3x3s2_fwd(const Tensor& x) {
+    check_nhwc_bf16(x, "x");
+    const long B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+    TORCH_CHECK(C % 8 == 0, "maxpool: C must be a multiple of 8");
+    const long Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    c10::hip::HIPGuard guard(x.device());
+    Tensor y = empty_nhwc(B, C, Ho, Wo, x);
+    Tensor arg = at::empty({B, Ho, Wo, C}, x.options().dtype(at::kByte));
+    launch_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), arg.data_ptr<uint8_t>(), B, H, W, C, Ho, Wo, cur_stream(x));
+    return {y, arg};
+}
+Tensor maxpool3x3s2_bwd(const Tensor& dy, const Tensor& arg, std::vector<int64_t> x_shape) {
+    check_nhwc_bf16(dy, "dy");
+    const long B = x_shape[0], C = x_shape[1], H = x_shape[2], W = x_shape[3];
+    const long Ho = dy.size(2), Wo = dy.size(3);
+    TORCH_CHECK(dy.size(0) == B && dy.size(1) == C && Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "maxpool bwd shape mismatch");
+    TORCH_CHECK(arg.is_cuda() && arg.scalar_type() == at::kByte && arg.is_contiguous() && arg.numel() == dy.numel(),
+                "argmax tensor mismatch");
+    c10::hip::HIPGuard guard(dy.device());
+    Tensor dx = empty_nhwc(B, C, H, W, dy);
+    launch_maxpool3x3s2_bwd(dy.data_ptr(), arg.data_ptr<uint8_t>(), dx.data_ptr(), B, H, W, C, Ho, Wo, cur_stream(dy));
+    return dx;
+}
+Tensor global_avgpool_fwd(const Tensor& x) {
+    check_nhwc_bf16(x, "x");
+    const long B = x.size(0), C = x.size(1), HW = x.size(2) * x.size(3);
+    TORCH_CHECK(C % 8 == 0, "avgpool: C must be a multiple of 8");
+    c10::hip::HIPGuard guard(x.device());
+    Tensor y = at::empty({B, C}, x.options().memory_format(at::MemoryFormat::Contiguous));
+    launch_global_avgpool_fwd(x.data_ptr(), y.data_ptr(), B, HW, C, cur_stream(x));
+    return y;
+}
+Tensor global_avgpool_bwd(const Tensor& dy, std::vector<int64_t> x_shape) {
+    TORCH_CHECK(dy.is_cuda() && dy.scalar_type() == at::kBFloat16 && dy.dim() == 2 && dy.is_contiguous(), "dy: expected contiguous bf16 [B,C]");
+    const long B = x_shape[0], C = x_shape[1], H = x_shape[2], W = x_shape[3];
+    TORCH_CHECK(dy.size(0) == B && dy.size(1) == C && C % 8 == 0, "avgpool bwd shape mismatch");
+    c10::hip::HIPGuard guard(dy.device());
+    Tensor dx = empty_nhwc(B, C, H, W, dy);
+    launch_global_avgpool_bwd(dy.data_ptr(), dx.data_ptr(), B, H * W, C, cur_stream(dy));
+    return dx;
+}
+
+// ------------------------------------------------------------------------------------- loss
+std::tuple<Tensor, Tensor> softmax_ce(const Tensor& logits, const Tensor& labels) {
+    TORCH_CHECK(logits.is_cuda() && logits.dim() == 2 && logits.is_contiguous(), "logits: expected contiguous GPU [B,N]");
+    TORCH_CHECK(logits.scalar_type() == at::kBFloat16 || logits.scalar_type() == at::kFloat, "logits: bf16 or fp32");
+    TORCH_CHECK(labels.is_cuda() && labels.scalar_type() == at::kLong && labels.is_contiguous() &&
+                    labels.numel() == logits.size(0),
+                "labels: expected contiguous int64 GPU [B]");
+    const long B = logits.size(0), N = logits.size(1);
+    c10::hip::HIPGuard guard(logits.device());
+    Tensor dlogits = at::empty_like(logits);
+    Tensor row_loss = at::empty({B}, logits.options().dtype(at::kFloat));
+    Tensor loss = at::empty({}, logits.options().dtype(at::kFloat));
+    launch_softmax_ce(logits.data_ptr(), logits.scalar_type() == at::kBFloat16 ? kBF16 : kF32,
+                      labels.data_ptr<int64_t>(), (int)B, (int)N, row_loss.data_ptr<float>(), dlogits.data_ptr(),
+                      loss.data_ptr<float>(), cur_stream(logits));
+    return {loss, dlogits};
+}
+
+// ------------------------------------------------------------------------------------- cast
+Tensor to_nhwc_bf16(const Tensor& x, double scale) {
+    TORCH_CHECK(x.is_cuda() && x.dim() == 4 && x.is_contiguous(), "x: expected contiguous 4-D GPU tensor");
+    c10::hip::HIPGuard guard(x.device());
+    if (x.scalar_type() == at::kFloat) {  // NCHW fp32
+        const long B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+        TORCH_CHECK((size_t)C * (W + 1) * 4 <= 64 * 1024, "to_nhwc_bf16: C*W too large for the LDS tile");
+        Tensor y = at::empty({B, C, H, W}, x.options().dtype(at::kBFloat16).memory_format(at::MemoryFormat::ChannelsLast));
+        launch_to_nhwc_bf16(x.data_ptr(), kF32, y.data_ptr(), B, C, H, W, (float)scale, cur_stream(x));
+        return y;
+    }
+    TORCH_CHECK(x.scalar_type() == at::kByte, "to_nhwc_bf16: fp32 NCHW or uint8 NHWC input");
+    const long B = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);  // NHWC uint8
+    Tensor y = at::empty({B, C, H, W}, x.options().dtype(at::kBFloat16).memory_format(at::MemoryFormat::ChannelsLast));
+    launch_to_nhwc_bf16(x.data_ptr(), kU8, y.data_ptr(), B, C, H, W, (float)scale, cur_stream(x));
+    return y;
+}
+
+// ----------------------------------------------------------------------------- multi-tensor
+struct Table {
+    std::vector<int64_t> key;
+    Tensor dev;
+    int ntensors = 0, nchunks = 0;
+};
+std::unordered_map<uint64_t, Table> g_tables;
+std::mutex g_tables_mu;  // the autograd thread (reducer hooks) and the main thread (optimizer) both use it
+
+uint64_t hash_key(const std::vector<int64_t>& k) {
+    uint64_t h = 1469598103934665603ull;
+    for (int64_t v : k) h = (h ^ (uint64_t)v) * 1099511628211ull;
+    return h;
+}
+
+// cols: up to 5 pointer columns (nullptr allowed); returns a cached device table
+const Table& get_table(const std::vector<std::vector<const Tensor*>>& cols, const std::vector<int64_t>& numels,
+                       const at::Device& dev) {
+    const size_t n = numels.size();
+    std::vector<int64_t> key;
+    key.reserve(n * (cols.size() + 1));
+    for (size_t i = 0; i < n; ++i) {
+        for (const auto& col : cols) key.push_back(col[i] ? (int64_t)(uintptr_t)col[i]->data_ptr() : 0);
+        key.push_back(numels[i]);
+    }
+    const uint64_t h = hash_key(key);
+    std::lock_guard<std::mutex> lock(g_tables_mu);
+    auto it = g_tables.find(h);
+    if (it != g_tables.end() && it->second.key == key) return it->second;
+    if (g_tables.size() > 256) g_tables.clear();
+    std::vector<int64_t> host;
+    host.resize(n * kMTCols, 0);
+    std::vector<int64_t> chunks;
+    for (size_t i = 0; i < n; ++i) {
+        for (size_t c = 0; c < cols.size(); ++c)
+            host[i * kMTCols + c] = cols[c][i] ? (int64_t)(uintptr_t)cols[c][i]->data_ptr() : 0;
+        host[i * kMTCols + 5] = numels[i];
+        host[i * kMTCols + 6] = (int64_t)chunks.size();
+        const int64_t nc = (numels[i] + kMTChunk - 1) / kMTChunk;
+        for (int64_t c = 0; c < nc; ++c) chunks.push_back(((int64_t)i << 32) | c);
+    }
+    Table t;
+    t.ntensors = (int)n;
+    t.nchunks = (int)chunks.size();
+    host.insert(host.end(), chunks.begin(), chunks.end());
+    Tensor cpu = at::empty({(long)host.size()}, at::TensorOptions().dtype(at::kLong));
+    std::memcpy(cpu.data_ptr<int64_t>(), host.data(), host.size() * sizeof(int64_t));
+    t.dev = cpu.to(dev);
+    t.key = std::move(key);
+    auto& slot = g_tables[h];
+    slot = std::move(t);
+    return slot;
+}
+
+void check_mt(const Tensor& t, at::ScalarType st, const char* name) {
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == st, name, ": wrong device/dtype");
+    TORCH_CHECK(t.is_non_overlapping_and_dense(), name, ": tensor must be dense");
+    TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, ": data pointer must be 16-B aligned");
+}
+
+int dtype_code(at::ScalarType st) {
+    TORCH_CHECK(st == at::kFloat || st == at::kBFloat16, "multi-tensor ops take fp32 or bf16");
+    return st == at::kFloat ? kF32 : kBF16;
+}
+
+// dsts[i] <- srcs[i] * scale; every pair dense with identical strides
+void multi_flatten(std::vector<Tensor> srcs, std::vector<Tensor> dsts, double scale) {
+    TORCH_CHECK(srcs.size() == dsts.size(), "multi_flatten: list size mismatch");
+    if (srcs.empty()) return;
+    const auto sst = srcs[0].scalar_type(), dst_t = dsts[0].scalar_type();
+    std::vector<std::vector<const Tensor*>> cols(2);
+    std::vector<int64_t> numels;
+    for (size_t i = 0; i < srcs.size(); ++i) {
+        check_mt(srcs[i], sst, "src");
+        check_mt(dsts[i], dst_t, "dst");
+        TORCH_CHECK(srcs[i].numel() == dsts[i].numel() && srcs[i].strides() == dsts[i].strides(),
+                    "multi_flatten: src/dst must have the same dense layout");
+        cols[0].push_back(&srcs[i]);
+        cols[1].push_back(&dsts[i]);
+        numels.push_back(srcs[i].numel());
+    }
+    c10::hip::HIPGuard guard(srcs[0].device());
+    const Table& t = get_table(cols, numels, srcs[0].device());
+    launch_multi_flatten(t.dev.data_ptr<int64_t>(), t.ntensors, t.nchunks, (float)scale, dtype_code(sst),
+                         dtype_code(dst_t), cur_stream(srcs[0]));
+}
+
+void fill_cols(const std::vector<Tensor>& ps, const std::vector<Tensor>& gs, const std::vector<Tensor>* ms,
+               const std::vector<Tensor>* vs, const std::vector<c10::optional<Tensor>>& lps,
+               std::vector<std::vector<const Tensor*>>& cols, std::vector<int64_t>& numels) {
+    const size_t n = ps.size();
+    TORCH_CHECK(gs.size() == n && lps.size() == n && (!ms || ms->size() == n) && (!vs || vs->size() == n),
+                "optimizer lists differ in length");
+    cols.assign(5, std::vector<const Tensor*>(n, nullptr));
+    const auto gst = gs[0].scalar_type();
+    for (size_t i = 0; i < n; ++i) {
+        check_mt(ps[i], at::kFloat, "param");
+        check_mt(gs[i], gst, "grad");
+        TORCH_CHECK(gs[i].numel() == ps[i].numel() && gs[i].strides() == ps[i].strides(), "grad layout != param layout");
+        cols[0][i] = &ps[i];
+        cols[1][i] = &gs[i];
+        if (ms) {
+            check_mt((*ms)[i], at::kFloat, "state");
+            TORCH_CHECK((*ms)[i].strides() == ps[i].strides(), "state layout != param layout");
+            cols[2][i] = &(*ms)[i];
+        }
+        if (vs) {
+            check_mt((*vs)[i], at::kFloat, "state");
+            TORCH_CHECK((*vs)[i].strides() == ps[i].strides(), "state layout != param layout");
+            cols[3][i] = &(*vs)[i];
+        }
+        if (lps[i].has_value() && lps[i]->defined()) {
+            check_mt(*lps[i], at::kBFloat16, "low-precision copy");
+            TORCH_CHECK(lps[i]->strides() == ps[i].strides(), "low-precision copy layout != param layout");
+            cols[4][i] = &*lps[i];
+        }
+        numels.push_back(ps[i].numel());
+    }
+}
+
+void multi_adam(std::vector<Tensor> ps, std::vector<Tensor> gs, std::vector<Tensor> ms, std::vector<Tensor> vs,
+                std::vector<c10::optional<Tensor>> lps, double lr, double beta1, double beta2, double eps,
+                double weight_decay, int64_t step, bool adamw, double grad_scale) {
+    if (ps.empty()) return;
+    std::vector<std::vector<const Tensor*>> cols;
+    std::vector<int64_t> numels;
+    fill_cols(ps, gs, &ms, &vs, lps, cols, numels);
+    c10::hip::HIPGuard guard(ps[0].device());
+    const Table& t = get_table(cols, numels, ps[0].device());
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc2 = 1.0 - std::pow(beta2, (double)step);
+    launch_multi_adam(t.dev.data_ptr<int64_t>(), t.ntensors, t.nchunks, (float)lr, (float)beta1, (float)beta2,
+                      (float)eps, (float)weight_decay, (float)bc1, (float)std::sqrt(bc2), adamw ? 1 : 0,
+                      (float)grad_scale, dtype_code(gs[0].scalar_type()), cur_stream(ps[0]));
+}
+
+void multi_sgd(std::vector<Tensor> ps, std::vector<Tensor> gs, std::vector<Tensor> bufs,
+               std::vector<c10::optional<Tensor>> lps, double lr, double momentum, double dampening,
+               double weight_decay, bool nesterov, bool first, double grad_scale) {
+    if (ps.empty()) return;
+    std::vector<std::vector<const Tensor*>> cols;
+    std::vector<int64_t> numels;
+    fill_cols(ps, gs, &bufs, nullptr, lps, cols, numels);
+    c10::hip::HIPGuard guard(ps[0].device());
+    const Table& t = get_table(cols, numels, ps[0].device());
+    launch_multi_sgd(t.dev.data_ptr<int64_t>(), t.ntensors, t.nchunks, (float)lr, (float)momentum, (float)dampening,
+                     (float)weight_decay, nesterov ? 1 : 0, first ? 1 : 0, (float)grad_scale,
+                     dtype_code(gs[0].scalar_type()), cur_stream(ps[0]));
+}
+
+}  // namespace
+
+void multi_flatten_tensors(std::vector<at::Tensor>& srcs, std::vector<at::Tensor>& dsts, double scale) {
+    multi_flatten(srcs, dsts, scale);
+}
+
+void bind_ops(pybind11::module& m) {
+    m.def("conv2d_fwd", &conv2d_fwd);
+    m.def("conv2d_dgrad", &conv2d_dgrad);
+    m.def("conv2d_wgrad", &conv2d_wgrad);
+    m.def("transpose_weight", &transpose_weight);
+    m.def("bn_stats", &bn_stats);
+    m.def("bn_finalize", &bn_finalize);
+    m.def("bn_apply_act", &bn_apply_act);
+    m.def("bn_bwd_reduce", &bn_bwd_reduce);
+    m.def("bn_bwd_elemt", &bn_bwd_elemt);
+    m.def("maxpool3x3s2_fwd", &maxpool3x3s2_fwd);
+    m.def("maxpool3x3s2_bwd", &maxpool3x3s2_bwd);
+    m.def("global_avgpool_fwd", &global_avgpool_fwd);
+    m.def("global_avgpool_bwd", &global_avgpool_bwd);
+    m.def("softmax_ce", &softmax_ce);
+    m.def("to_nhwc_bf16", &to_nhwc_bf16);
+    m.def("multi_flatten", &multi_flatten);
+    m.def("multi_adam", &multi_adam);
+    m.def("multi_sgd", &multi_sgd);
+}
+
+}  // namespace pdt

@@ -1,0 +1,304 @@
+// BatchNorm training kernels for NHWC bf16 activations.
+//
+// Reference stack per BN layer: batch_norm_stats, gather_stats_with_counts, batch_norm_elemt,
+// relu, (add), and in backward relu_backward, batch_norm_backward_reduce, backward_elemt.
+// Here:  stats (only when the producing conv did not emit them in its epilogue)
+//        finalize            mean / invstd / running stats, one tiny launch, no host sync
+//        apply               normalise + affine (+ residual) (+ ReLU), one pass
+//        bwd_reduce          ReLU mask fused into the two BN reductions
+//        bwd_elemt           grad_input (+ the masked gradient for the residual branch)
+// Access pattern: NHWC makes the channel the fastest axis, so a thread owns 8 consecutive
+// channels (one 16 B load) and walks rows; its per-channel coefficients stay in registers.
+// The cross-row reductions are deterministic (LDS tree + partial slab, no float atomics).
+#include "common.h"
+#include "kernels.h"
+
+namespace pdt {
+namespace {
+
+constexpr int kThreads = 256;
+
+struct Map {
+    int G;       // channel groups of 8 per row (C/8), power of two <= 256
+    int R;       // rows covered per pass by one block
+    int cg, rl;  // this thread's channel group / row lane
+};
+__device__ __forceinline__ Map make_map(int C) {
+    Map m;
+    m.G = C >> 3;
+    m.R = kThreads / m.G;
+    m.cg = threadIdx.x % m.G;
+    m.rl = threadIdx.x / m.G;
+    return m;
+}
+__device__ __forceinline__ void block_rows(long M, long& r0, long& r1) {
+    const long per = (M + gridDim.x - 1) / gridDim.x;
+    r0 = (long)blockIdx.x * per;
+    r1 = r0 + per < M ? r0 + per : M;
+}
+__device__ __forceinline__ bf16x8 ld8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void st8(bf16* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+__device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
+// Two 8-channel accumulators per thread -> slab[part][2][C]
+__device__ __forceinline__ void block_reduce_store(const Map& m, int C, const float (&s0)[8], const float (&s1)[8],
+                                                   float* slab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);  // [R][G][16]
+    float* mine = red + ((long)m.rl * m.G + m.cg) * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mine[k] = s0[k];
+        mine[8 + k] = s1[k];
+    }
+    __syncthreads();
+    // thread t < 2C sums column t over the R row lanes
+    for (int t = threadIdx.x; t < 2 * C; t += kThreads) {
+        const int which = t / C, c = t % C;
+        const int cg = c >> 3, k = c & 7;
+        float a = 0.f;
+        for (int r = 0; r < m.R; ++r) a += red[((long)r * m.G + cg) * 16 + which * 8 + k];
+        slab[(long)blockIdx.x * 2 * C + t] = a;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_stats(const bf16* __restrict__ x, long M, int C,
+                                                       float* __restrict__ slab) {
+    const Map m = make_map(C);
+    long r0, r1;
+    block_rows(M, r0, r1);
+    float s[8] = {0}, q[8] = {0};
+    for (long r = r0 + m.rl; r < r1; r += m.R) {
+        const bf16x8 v = ld8(x + r * C + m.cg * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float f = (float)v[k];
+            s[k] += f;
+            q[k] += f * f;
+        }
+    }
+    block_reduce_store(m, C, s, q, slab);
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restrict__ stats, int C, float count,
+                                                          const float* __restrict__ count_dev, float eps,
+                                                          float momentum, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ mean,
+                                                          float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float n = count_dev ? count_dev[0] : count;
+    const float mu = stats[c] / n;
+    float var = stats[C + c] / n - mu * mu;
+    var = var > 0.f ? var : 0.f;
+    mean[c] = mu;
+    invstd[c] = rsqrtf(var + eps);
+    if (running_mean) {
+        const float unbiased = var * (n / fmaxf(n - 1.f, 1.f));
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ x, const bf16* __restrict__ res,
+                                                       bf16* __restrict__ z, long M, int C,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta) {
+    const Map m = make_map(C);
+    long r0, r1;
+    block_rows(M, r0, r1);
+    float a[8], b[8];
+    {
+        float mu[8], is[8], ga[8], be[8];
+        ld8f(mean + m.cg * 8, mu);
+        ld8f(invstd + m.cg * 8, is);
+        ld8f(gamma + m.cg * 8, ga);
+        ld8f(beta + m.cg * 8, be);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a[k] = is[k] * ga[k];
+            b[k] = be[k] - mu[k] * a[k];
+        }
+    }
+    for (long r = r0 + m.rl; r < r1; r += m.R) {
+        const long off = r * C + m.cg * 8;
+        const bf16x8 v = ld8(x + off);
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (float)v[k] * a[k] + b[k];
+        if (RES) {
+            const bf16x8 rv = ld8(res + off);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] += (float)rv[k];
+        }
+        if (RELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = fmaxf(o[k], 0.f);
+        }
+        st8(z + off, o);
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const bf16* __restrict__ dz, const bf16* __restrict__ z,
+                                                            const bf16* __restrict__ x, long M, int C,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            float* __restrict__ slab) {
+    const Map m = make_map(C);
+    long r0, r1;
+    block_rows(M, r0, r1);
+    float mu[8], is[8];
+    ld8f(mean + m.cg * 8, mu);
+    ld8f(invstd + m.cg * 8, is);
+    float s0[8] = {0}, s1[8] = {0};
+    for (long r = r0 + m.rl; r < r1; r += m.R) {
+        const long off = r * C + m.cg * 8;
+        const bf16x8 g = ld8(dz + off);
+        const bf16x8 xv = ld8(x + off);
+        bf16x8 zv;
+        if (RELU) zv = ld8(z + off);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float gg = (float)g[k];
+            if (RELU) gg = ((float)zv[k] > 0.f) ? gg : 0.f;
+            s0[k] += gg;
+            s1[k] += gg * ((float)xv[k] - mu[k]) * is[k];
+        }
+    }
+    block_reduce_store(m, C, s0, s1, slab);
+}
+
+// dx = k1*dzm + k2*x + k3 with per-channel k's (see host comment); dres = dzm
+template <bool RELU, bool DRES>
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restrict__ dz, const bf16* __restrict__ z,
+                                                           const bf16* __restrict__ x, bf16* __restrict__ dx,
+                                                           bf16* __restrict__ dres, long M, int C,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, float count,
+                                                           const float* __restrict__ count_dev) {
+    const Map m = make_map(C);
+    long r0, r1;
+    block_rows(M, r0, r1);
+    const float invn = 1.f / (count_dev ? count_dev[0] : count);
+    float k1[8], k2[8], k3[8];
+    {
+        float mu[8], is[8], ga[8], sa[8], sb[8];
+        ld8f(mean + m.cg * 8, mu);
+        ld8f(invstd + m.cg * 8, is);
+        ld8f(gamma + m.cg * 8, ga);
+        ld8f(sums + m.cg * 8, sa);
+        ld8f(sums + C + m.cg * 8, sb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float g_is = ga[k] * is[k];
+            const float c1 = sa[k] * invn, c2 = sb[k] * invn;
+            k1[k] = g_is;
+            k2[k] = -g_is * c2 * is[k];
+            k3[k] = g_is * (c2 * is[k] * mu[k] - c1);
+        }
+    }
+    for (long r = r0 + m.rl; r < r1; r += m.R) {
+        const long off = r * C + m.cg * 8;
+        const bf16x8 g = ld8(dz + off);
+        const bf16x8 xv = ld8(x + off);
+        bf16x8 zv;
+        if (RELU) zv = ld8(z + off);
+        float o[8], gm[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float gg = (float)g[k];
+            if (RELU) gg = ((float)zv[k] > 0.f) ? gg : 0.f;
+            gm[k] = gg;
+            o[k] = k1[k] * gg + k2[k] * (float)xv[k] + k3[k];
+        }
+        st8(dx + off, o);
+        if (DRES) st8(dres + off, gm);
+    }
+}
+
+int grid_for(long M, int C) {
+    const int R = kThreads / (C >> 3);
+    long parts = (M + (long)R * 16 - 1) / ((long)R * 16);
+    if (parts < 1) parts = 1;
+    if (parts > 1024) parts = 1024;
+    return (int)parts;
+}
+
+}  // namespace
+
+int bn_parts(long M, int C) { return grid_for(M, C); }
+
+void launch_bn_stats(const void* x, long M, int C, float* slab, int parts, hipStream_t s) {
+    const size_t lds = (size_t)kThreads * 16 * sizeof(float);
+    hipLaunchKernelGGL(k_bn_stats, dim3(parts), dim3(kThreads), lds, s, (const bf16*)x, M, C, slab);
+}
+
+void launch_bn_finalize(const float* stats, int C, float count, const float* count_dev, float eps, float momentum,
+                        float* running_mean, float* running_var, float* mean, float* invstd, hipStream_t s) {
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, s, stats, C, count,
+                       count_dev, eps, momentum, running_mean, running_var, mean, invstd);
+}
+
+void launch_bn_apply(const void* x, const void* residual, void* z, long M, int C, const float* mean,
+                     const float* invstd, const float* gamma, const float* beta, int relu, hipStream_t s) {
+    const int R = kThreads / (C >> 3);
+    long blocks = (M + (long)R * 8 - 1) / ((long)R * 8);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((int)blocks), block(kThreads);
+#define PDT_APPLY(RELU, RES)                                                                                    \
+    hipLaunchKernelGGL((k_bn_apply<RELU, RES>), grid, block, 0, s, (const bf16*)x, (const bf16*)residual, (bf16*)z, \
+                       M, C, mean, invstd, gamma, beta)
+    if (relu && residual) PDT_APPLY(true, true);
+    else if (relu) PDT_APPLY(true, false);
+    else if (residual) PDT_APPLY(false, true);
+    else PDT_APPLY(false, false);
+#undef PDT_APPLY
+}
+
+void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, int C, const float* mean,
+                          const float* invstd, int relu, float* slab, int parts, hipStream_t s) {
+    const size_t lds = (size_t)kThreads * 16 * sizeof(float);
+    if (relu)
+        hipLaunchKernelGGL((k_bn_bwd_reduce<true>), dim3(parts), dim3(kThreads), lds, s, (const bf16*)dz,
+                           (const bf16*)z, (const bf16*)x, M, C, mean, invstd, slab);
+    else
+        hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(parts), dim3(kThreads), lds, s, (const bf16*)dz,
+                           (const bf16*)z, (const bf16*)x, M, C, mean, invstd, slab);
+}
+
+void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx, void* dres, long M, int C,
+                         const float* mean, const float* invstd, const float* gamma, const float* sums,
+                         float count, const float* count_dev, int relu, hipStream_t s) {
+    const int R = kThreads / (C >> 3);
+    long blocks = (M + (long)R * 8 - 1) / ((long)R * 8);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((int)blocks), block(kThreads);
+#define PDT_ELEMT(RELU, DRES)                                                                                  \
+    hipLaunchKernelGGL((k_bn_bwd_elemt<RELU, DRES>), grid, block, 0, s, (const bf16*)dz, (const bf16*)z,       \
+                       (const bf16*)x, (bf16*)dx, (bf16*)dres, M, C, mean, invstd, gamma, sums, count, count_dev)
+    if (relu && dres) PDT_ELEMT(true, true);
+    else if (relu) PDT_ELEMT(true, false);
+    else if (dres) PDT_ELEMT(false, true);
+    else PDT_ELEMT(false, false);
+#undef PDT_ELEMT
+}
+
+}  // namespace pdt

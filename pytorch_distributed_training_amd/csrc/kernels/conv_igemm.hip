@@ -1,0 +1,285 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores.
+//
+//   Out[b, i*os+ooh, j*os+oow, n] = sum_t sum_c In[b, i*is+dh[t], j*is+dw[t], c] * Wt[n][wslot[t]][c]
+//
+// One kernel serves the forward conv (In = x, taps = (r,s), is = stride) and the data gradient
+// (In = dY, Wt = transposed weights, taps = the (r,s) that hit this output-parity class), see the
+// host wrappers.  GEMM view: M = B*nOH*nOW output pixels, N = output channels, K = taps*C.
+//
+// Design for CDNA4 (wave64, 4 SIMDs/CU, 160 KiB LDS, MFMA 32x32x16 bf16):
+//  * NHWC bf16 activations and [N][taps][C] weights make BOTH operands K-contiguous: every lane
+//    moves 16 B (8 channels) per load, a tile row is one 128 B line (BK = 64 channels).
+//  * zero padding comes from the buffer descriptor's range check (out-of-image taps get an
+//    out-of-range offset and load zeros): no branches in the load path.
+//  * 256 threads = 4 waves; block tile BM x BN (128x128 or 128x64), each wave owns a grid of
+//    32x32 MFMA tiles with fp32 accumulators in registers.
+//  * global -> registers -> LDS staging, double buffered: the loads of K-step k+1 are issued
+//    before the MFMAs of step k and written to the other LDS buffer after them; one barrier
+//    per K-step.  LDS rows are 128 B with the 16-B chunk XOR-swizzled by (row>>1)&7 so the
+//    ds_read_b128 fragment reads are bank-conflict free.
+//  * epilogue: accumulators are rounded to bf16, per-channel [sum, sum_sq] of the rounded
+//    values are reduced in registers/LDS and written to a per-m-tile slab (BatchNorm
+//    statistics for free), and the tile is staged through LDS so global stores are 16 B per
+//    lane on full rows.
+//  * block -> tile map is XCD-aware: the 8 XCDs get contiguous tile ranges, n-tiles fastest,
+//    so blocks sharing an activation tile hit the same 4 MiB L2.
+#include "common.h"
+#include "kernels.h"
+
+namespace pdt {
+namespace {
+
+constexpr int BK = 64;            // channels per K-step
+constexpr int ROWB = BK * 2;      // bytes per LDS row (128)
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                       bf16* __restrict__ y, const ConvGeom g,
+                                                       float* __restrict__ stats_slab, int m_tiles, int n_tiles,
+                                                       uint32_t x_bytes, uint32_t w_bytes) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                  // [2][BM][128 B]
+    char* Bs = smem + 2 * A_BYTES;    // [2][BN][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = tid >> 3, chunk = tid & 7;
+
+    // XCD-aware, bijective block -> tile map (blocks b and b+8 share an XCD)
+    const int total = m_tiles * n_tiles;
+    int tile;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+        const int q = total >> 3, r = total & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tile_n = tile % n_tiles, tile_m = tile / n_tiles;
+    const long M = (long)g.B * g.nOH * g.nOW;
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, x_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(w, w_bytes);
+
+    // per-row gather state of the A rows this thread stages
+    int rowpix[PA], rih[PA], riw[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const long m = (long)tile_m * BM + p * 32 + lrow;
+        if (m < M) {
+            const int j = (int)(m % g.nOW);
+            const long t1 = m / g.nOW;
+            const int i = (int)(t1 % g.nOH);
+            const int b = (int)(t1 / g.nOH);
+            rowpix[p] = b * g.Hin * g.Win;
+            rih[p] = i * g.is;
+            riw[p] = j * g.is;
+        } else {
+            rowpix[p] = 0;
+            rih[p] = -100000;  // every tap lands outside the image -> zeros
+            riw[p] = 0;
+        }
+    }
+    uint32_t wrow[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int n = tile_n * BN + p * 32 + lrow;
+        wrow[p] = (n < g.N) ? (uint32_t)n * (uint32_t)g.wtaps : 0xffffffffu;
+    }
+
+    bf16x8 ra[PA], rb[PB];
+    auto gload = [&](int t, int c0) {
+        const int dh = g.dh[t], dw = g.dw[t], ws = g.wslot[t];
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int hi = rih[p] + dh, wi = riw[p] + dw;
+            const bool ok = (unsigned)hi < (unsigned)g.Hin && (unsigned)wi < (unsigned)g.Win;
+            const uint32_t off = (uint32_t)(((rowpix[p] + hi * g.Win + wi) * g.C + c0 + chunk * 8) * 2);
+            ra[p] = buffer_load_bf16x8(rx, ok ? off : kOOB);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const uint32_t off = ((wrow[p] + (uint32_t)ws) * (uint32_t)g.C + (uint32_t)(c0 + chunk * 8)) * 2u;
+            rb[p] = buffer_load_bf16x8(rw, wrow[p] != 0xffffffffu ? off : kOOB);
+        }
+    };
+    auto lds_store = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+            *reinterpret_cast<bf16x8*>(As + buf * A_BYTES + lds_off(p * 32 + lrow, chunk)) = ra[p];
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            *reinterpret_cast<bf16x8*>(Bs + buf * B_BYTES + lds_off(p * 32 + lrow, chunk)) = rb[p];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int cpt = g.C / BK;  // K-steps per tap
+    const int nks = g.ntaps * cpt;
+    int t_next = 0, c_next = 0;
+    gload(0, 0);
+    lds_store(0);
+    __syncthreads();
+
+    const int arow0 = wm * (BM / WM) + (lane & 31);
+    const int brow0 = wn * (BN / WN) + (lane & 31);
+    const int khalf = lane >> 5;
+
+    for (int ks = 0; ks < nks; ++ks) {
+        const int cur = ks & 1;
+        const bool more = ks + 1 < nks;
+        if (more) {
+            c_next += BK;
+            if (c_next == g.C) {
+                c_next = 0;
+                ++t_next;
+            }
+            gload(t_next, c_next);
+        }
+        const char* Ab = As + cur * A_BYTES;
+        const char* Bb = Bs + cur * B_BYTES;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(Ab + lds_off(arow0 + i * 32, 2 * s + khalf));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + lds_off(brow0 + j * 32, 2 * s + khalf));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) lds_store(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // LDS reuse: out tile [BM][BN] bf16 at 0, stats scratch [WM][BN][2] fp32 after it.
+    constexpr int OPITCH = BN * 2;
+    char* Os = smem;
+    float* Ss = reinterpret_cast<float*>(smem + BM * OPITCH);
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        float csum = 0.f, csq = 0.f;
+        const int col = wn * (BN / WN) + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = wm * (BM / WM) + i * 32 + 4 * khalf;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const bf16 b0 = (bf16)acc[i][j][r], b1 = (bf16)acc[i][j][r + 1];
+                const float f0 = (float)b0, f1 = (float)b1;
+                csum += f0 + f1;
+                csq += f0 * f0 + f1 * f1;
+                const uint32_t u0 = __builtin_bit_cast(uint16_t, b0), u1 = __builtin_bit_cast(uint16_t, b1);
+                const uint32_t recv = (uint32_t)__shfl_xor((int)(odd ? u0 : u1), 1, 64);
+                // even lane: row r, cols (n, n+1);  odd lane: row r+1, cols (n-1, n)
+                const uint32_t packed = odd ? (recv | (u1 << 16)) : (u0 | (recv << 16));
+                const int row = rbase + (r & 3) + 8 * (r >> 2) + (odd ? 1 : 0);
+                const int c2 = odd ? col - 1 : col;
+                *reinterpret_cast<uint32_t*>(Os + row * OPITCH + c2 * 2) = packed;
+            }
+        }
+        if (stats_slab != nullptr) {
+            csum += __shfl_xor(csum, 32, 64);
+            csq += __shfl_xor(csq, 32, 64);
+            if (lane < 32) {
+                Ss[(wm * BN + col) * 2 + 0] = csum;
+                Ss[(wm * BN + col) * 2 + 1] = csq;
+            }
+        }
+    }
+    __syncthreads();
+
+    if (stats_slab != nullptr && tid < BN) {
+        const int n = tile_n * BN + tid;
+        if (n < g.N) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < WM; ++k) {
+                s0 += Ss[(k * BN + tid) * 2 + 0];
+                s1 += Ss[(k * BN + tid) * 2 + 1];
+            }
+            float* dst = stats_slab + (long)tile_m * 2 * g.N;
+            dst[n] = s0;
+            dst[g.N + n] = s1;
+        }
+    }
+
+    constexpr int CH = BN / 8;          // 16-B chunks per output row
+    constexpr int RPP = 256 / CH;       // rows per pass
+    const int orow = tid / CH, och = tid % CH;
+    const bool dense = (g.os == 1 && g.nOH == g.Hout && g.nOW == g.Wout);
+    const int ncol = tile_n * BN + och * 8;
+#pragma unroll
+    for (int p = 0; p < BM / RPP; ++p) {
+        const int row = p * RPP + orow;
+        const long m = (long)tile_m * BM + row;
+        if (m < M && ncol < g.N) {
+            long pix;
+            if (dense) {
+                pix = m;
+            } else {
+                const int j = (int)(m % g.nOW);
+                const long t1 = m / g.nOW;
+                const int i = (int)(t1 % g.nOH);
+                const long b = t1 / g.nOH;
+                pix = (b * g.Hout + (i * g.os + g.ooh)) * g.Wout + (j * g.os + g.oow);
+            }
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * OPITCH + och * 16);
+            *reinterpret_cast<bf16x8*>(y + pix * g.N + ncol) = v;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_cfg(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab, hipStream_t s) {
+    const long M = (long)g.B * g.nOH * g.nOW;
+    const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = (g.N + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * ROWB;
+    const uint32_t xb = (uint32_t)((long)g.B * g.Hin * g.Win * g.C * 2);
+    const uint32_t wb = (uint32_t)((long)g.N * g.wtaps * g.C * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<BM, BN, WM, WN>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), dim3(m_tiles * n_tiles), dim3(256), lds, s, (const bf16*)x,
+                       (const bf16*)w, (bf16*)y, g, stats_slab, m_tiles, n_tiles, xb, wb);
+}
+
+inline bool use_bn128(const ConvGeom& g) { return g.N % 128 == 0; }
+
+}  // namespace
+
+int conv_igemm_m_tiles(const ConvGeom& g, int* bm_out) {
+    const long M = (long)g.B * g.nOH * g.nOW;
+    if (bm_out) *bm_out = 128;
+    return (int)((M + 127) / 128);
+}
+
+void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab,
+                       hipStream_t s) {
+    if (use_bn128(g))
+        launch_cfg<128, 128, 2, 2>(x, w, y, g, stats_slab, s);
+    else
+        launch_cfg<128, 64, 4, 1>(x, w, y, g, stats_slab, s);
+}
+
+}  // namespace pdt

@@ -1,0 +1,255 @@
+// Convolution weight gradient on the gfx950 matrix cores.
+//
+//   dW[n][r][s][c] = sum_m dY[m][n] * X[pix(m, r, s)][c],   m = (b, ho, wo)
+//
+// GEMM view: rows = n (Cout), cols = c (Cin) per tap (r,s), and the reduction runs over the
+// B*Ho*Wo output pixels: enormous K, small output.  Both operands are K-STRIDED in memory
+// (NHWC keeps channels contiguous, not pixels), so tiles are staged row-major [pixel][channel]
+// in LDS and the MFMA fragments are fetched with the CDNA4 transposing LDS read
+// (ds_read_b64_tr_b16): no transposed copies of dY / X are ever materialised.
+//
+//  * block = 256 threads = 2x2 waves, output tile TN x TC (64/128 each) of one tap, MFMA
+//    32x32x16 bf16 with fp32 accumulators.
+//  * split-K over pixels: grid = tiles x splits; each split writes its fp32 partial tile to a
+//    slab [split][N][taps][C] with plain stores, and a second launch sums the slab rows in a
+//    fixed order: deterministic, no float atomics (which cap at ~1.3 TB/s chip-wide and lose
+//    run-to-run reproducibility).
+//  * LDS rows are 128/256 B with an XOR swizzle of the 16-B chunk chosen so that the four
+//    rows x 64 B that one half-wave touches in a transposed read fall on 64 distinct banks.
+//  * zero padding and the ragged end of a split come from the buffer range check.
+#include "common.h"
+#include "kernels.h"
+
+namespace pdt {
+namespace {
+
+constexpr int KM = 64;  // pixels (reduction rows) per K-step
+
+struct FastDiv {
+    uint32_t mlo, shift, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t L = 0;
+    while ((1u << L) < d) ++L;
+    const unsigned __int128 one = 1;
+    const unsigned __int128 magic = ((one << (32 + L)) + d - 1) / d;  // ceil(2^(32+L) / d), in [2^32, 2^33)
+    f.mlo = (uint32_t)(magic - (one << 32));
+    f.shift = L;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {  // exact for n < 2^31
+    return (n + __umulhi(n, f.mlo)) >> f.shift;
+}
+
+template <int RB>
+__device__ __forceinline__ int swz_off(int row, int ch) {
+    if constexpr (RB == 256) {
+        return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+    } else {
+        return row * 128 + ((ch ^ (((row >> 1) & 1) << 2)) << 4);
+    }
+}
+
+typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+
+// fragment for MFMA 32x32x16 from a row-major [k][col] LDS tile: lane l gets
+// elements (k = 8*(l>>5) + 0..7, col = colbase + (l&31)).
+template <int RB>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int krow0, int colbase, int lane) {
+    const int gl = lane & 15, q = gl >> 2, p = gl & 3;
+    const int col = colbase + ((lane >> 4) & 1) * 16 + p * 4;
+    const int row = krow0 + 8 * (lane >> 5) + q;
+    const int o0 = swz_off<RB>(row, col >> 3) + (col & 7) * 2;
+    const int o1 = swz_off<RB>(row + 4, col >> 3) + (col & 7) * 2;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + o0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + o1));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+struct WgradArgs {
+    int B, Hin, Win, C, Hout, Wout, N, KH, KW, stride, pad;
+    int n_tiles, c_tiles, splits;
+    long M, m_per_split;
+    FastDiv div_wo, div_howo;
+    uint32_t x_bytes, dy_bytes;
+};
+
+template <int TNW, int TCW>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                       float* __restrict__ slab, const WgradArgs a) {
+    constexpr int RBN = TNW * 2, RBC = TCW * 2;        // LDS row bytes
+    constexpr int CHN = TNW / 8, CHC = TCW / 8;        // 16-B chunks per row
+    constexpr int RPN = 256 / CHN, RPC = 256 / CHC;    // rows per staging pass
+    constexpr int PN = KM / RPN, PC = KM / RPC;        // passes per K-step
+    constexpr int TM = TNW / 64, TC = TCW / 64;        // 32x32 MFMA tiles per wave (2x2 waves)
+    constexpr int N_BYTES = KM * RBN, C_BYTES = KM * RBC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ns = smem;                 // [2][KM][RBN]  dY tile
+    char* Cs = smem + 2 * N_BYTES;   // [2][KM][RBC]  X tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1;
+
+    // block -> (split, tap, n tile, c tile); tiles of one split are adjacent so the dY / X rows
+    // they share are hot in L2
+    int bid = blockIdx.x;
+    const int tile_c = bid % a.c_tiles;
+    bid /= a.c_tiles;
+    const int tile_n = bid % a.n_tiles;
+    bid /= a.n_tiles;
+    const int T = a.KH * a.KW;
+    const int tap = bid % T;
+    const int split = bid / T;
+    const int r = tap / a.KW, s = tap % a.KW;
+
+    const long m_begin = (long)split * a.m_per_split;
+    long m_end = m_begin + a.m_per_split;
+    if (m_end > a.M) m_end = a.M;
+
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, a.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, a.x_bytes);
+
+    const int nrow = tid / CHN, nch = tid % CHN;
+    const int crow = tid / CHC, cch = tid % CHC;
+    const int n0 = tile_n * TNW, c0 = tile_c * TCW;
+    const bool n_ok = (n0 + nch * 8) < a.N;
+    const bool c_ok = (c0 + cch * 8) < a.C;
+
+    bf16x8 rn[PN], rc[PC];
+    auto gload = [&](long mbase) {
+#pragma unroll
+        for (int p = 0; p < PN; ++p) {
+            const long m = mbase + p * RPN + nrow;
+            const uint32_t off = (uint32_t)((m * a.N + n0 + nch * 8) * 2);
+            rn[p] = buffer_load_bf16x8(rdy, (m < m_end && n_ok) ? off : kOOB);
+        }
+#pragma unroll
+        for (int p = 0; p < PC; ++p) {
+            const long m = mbase + p * RPC + crow;
+            uint32_t off = kOOB;
+            if (m < m_end && c_ok) {
+                const uint32_t mm = (uint32_t)m;
+                const uint32_t b = fdiv(mm, a.div_howo);
+                const uint32_t rem = mm - b * a.div_howo.d;
+                const uint32_t ho = fdiv(rem, a.div_wo);
+                const uint32_t wo = rem - ho * a.div_wo.d;
+                const int hi = (int)ho * a.stride - a.pad + r;
+                const int wi = (int)wo * a.stride - a.pad + s;
+                if ((unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win)
+                    off = (uint32_t)(((((long)b * a.Hin + hi) * a.Win + wi) * a.C + c0 + cch * 8) * 2);
+            }
+            rc[p] = buffer_load_bf16x8(rx, off);
+        }
+    };
+    auto lds_store = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PN; ++p)
+            *reinterpret_cast<bf16x8*>(Ns + buf * N_BYTES + swz_off<RBN>(p * RPN + nrow, nch)) = rn[p];
+#pragma unroll
+        for (int p = 0; p < PC; ++p)
+            *reinterpret_cast<bf16x8*>(Cs + buf * C_BYTES + swz_off<RBC>(p * RPC + crow, cch)) = rc[p];
+    };
+
+    f32x16 acc[TM][TC];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    const long span = m_end - m_begin;
+    const int nks = span > 0 ? (int)((span + KM - 1) / KM) : 0;
+    if (nks > 0) {
+        gload(m_begin);
+        lds_store(0);
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int cur = ks & 1;
+        const bool more = ks + 1 < nks;
+        if (more) gload(m_begin + (long)(ks + 1) * KM);
+        const char* Nb = Ns + cur * N_BYTES;
+        const char* Cb = Cs + cur * C_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < KM / 16; ++kk) {
+            bf16x8 af[TM], bfr[TC];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = tr_frag<RBN>(Nb, kk * 16, wn * (TNW / 2) + i * 32, lane);
+#pragma unroll
+            for (int j = 0; j < TC; ++j) bfr[j] = tr_frag<RBC>(Cb, kk * 16, wc * (TCW / 2) + j * 32, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TC; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) lds_store(cur ^ 1);
+        __syncthreads();
+    }
+
+    // partial tile -> slab[split][n][tap][c]  (lane = column c: 128-B contiguous segments)
+    float* out = slab + (long)split * a.N * T * a.C;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+            const int c = c0 + wc * (TCW / 2) + j * 32 + (lane & 31);
+            const int nb = n0 + wn * (TNW / 2) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int n = nb + (k & 3) + 8 * (k >> 2);
+                if (n < a.N && c < a.C) out[((long)n * T + tap) * a.C + c] = acc[i][j][k];
+            }
+        }
+}
+
+template <int TNW, int TCW>
+void launch_cfg(const void* dy, const void* x, float* slab, const WgradGeom& g, hipStream_t s) {
+    WgradArgs a;
+    a.B = g.B; a.Hin = g.Hin; a.Win = g.Win; a.C = g.C; a.Hout = g.Hout; a.Wout = g.Wout; a.N = g.N;
+    a.KH = g.KH; a.KW = g.KW; a.stride = g.stride; a.pad = g.pad;
+    a.n_tiles = (g.N + TNW - 1) / TNW;
+    a.c_tiles = (g.C + TCW - 1) / TCW;
+    a.splits = g.splits;
+    a.M = (long)g.B * g.Hout * g.Wout;
+    long per = (a.M + g.splits - 1) / g.splits;
+    per = (per + KM - 1) / KM * KM;
+    a.m_per_split = per;
+    a.div_wo = make_fastdiv((uint32_t)g.Wout);
+    a.div_howo = make_fastdiv((uint32_t)(g.Hout * g.Wout));
+    a.x_bytes = (uint32_t)((long)g.B * g.Hin * g.Win * g.C * 2);
+    a.dy_bytes = (uint32_t)(a.M * g.N * 2);
+    const size_t lds = (size_t)2 * KM * (TNW + TCW) * 2;
+    const int grid = a.n_tiles * a.c_tiles * g.KH * g.KW * g.splits;
+    hipLaunchKernelGGL((k_conv_wgrad<TNW, TCW>), dim3(grid), dim3(256), lds, s, (const bf16*)dy, (const bf16*)x, slab,
+                       a);
+}
+
+inline int tile_w(int dim) { return dim % 128 == 0 ? 128 : 64; }
+
+}  // namespace
+
+int conv_wgrad_splits(const WgradGeom& g) {
+    const int tn = tile_w(g.N), tc = tile_w(g.C);
+    const long tiles = (long)((g.N + tn - 1) / tn) * ((g.C + tc - 1) / tc) * g.KH * g.KW;
+    const long M = (long)g.B * g.Hout * g.Wout;
+    long splits = (1024 + tiles - 1) / tiles;
+    const long max_splits = (M + 4 * KM - 1) / (4 * KM);  // at least 4 K-steps per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 512) splits = 512;
+    return (int)splits;
+}
+
+void launch_conv_wgrad(const void* dy, const void* x, float* slab, const WgradGeom& g, hipStream_t s) {
+    const int tn = tile_w(g.N), tc = tile_w(g.C);
+    if (tn == 128 && tc == 128) launch_cfg<128, 128>(dy, x, slab, g, s);
+    else if (tn == 128) launch_cfg<128, 64>(dy, x, slab, g, s);
+    else if (tc == 128) launch_cfg<64, 128>(dy, x, slab, g, s);
+    else launch_cfg<64, 64>(dy, x, slab, g, s);
+}
+
+}  // namespace pdt

@@ -1,0 +1,323 @@
+// Memory-bound multi-tensor kernels: bucket flatten (+1/W scale, +cast), fused Adam/AdamW,
+// fused SGD-momentum, input layout cast, weight transpose, slab reduction.
+//
+// Reference behaviour being replaced: c10d's per-tensor copy_/div_ into the bucket and ATen's
+// ~10 _foreach_* launches per Adam step.  Here ONE launch walks a
+// device-resident table (cached on the host while the pointers stay the same), 16 B per lane,
+// fp32 math, and the optimizer also refreshes the bf16 working copy of the weights.
+#include "common.h"
+#include "kernels.h"
+
+namespace pdt {
+
+namespace {
+
+struct Row {
+    int64_t p0, p1, p2, p3, p4, numel, chunk_start, flags;
+};
+
+__device__ __forceinline__ void locate(const int64_t* table, int ntensors, int chunk, const Row*& row, long& base) {
+    const int64_t e = table[(long)ntensors * kMTCols + chunk];
+    const int t = (int)(e >> 32);
+    const int local = (int)(e & 0xffffffff);
+    row = reinterpret_cast<const Row*>(table) + t;
+    base = (long)local * kMTChunk;
+}
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, long i, long n, float (&v)[4]);
+
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, long i, long n, float (&v)[4]) {
+    if (i + 4 <= n) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + i);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (i + k < n) ? p[i + k] : 0.f;
+    }
+}
+template <>
+__device__ __forceinline__ void load4<bf16>(const bf16* p, long i, long n, float (&v)[4]) {
+    if (i + 4 <= n) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(p + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (float)t[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (i + k < n) ? (float)p[i + k] : 0.f;
+    }
+}
+__device__ __forceinline__ void store4(float* p, long i, long n, const float (&v)[4]) {
+    if (i + 4 <= n) {
+        f32x4 t = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p + i) = t;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k < n) p[i + k] = v[k];
+    }
+}
+__device__ __forceinline__ void store4(bf16* p, long i, long n, const float (&v)[4]) {
+    if (i + 4 <= n) {
+        bf16x4 t = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(p + i) = t;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k < n) p[i + k] = (bf16)v[k];
+    }
+}
+
+// row: p0 = src, p1 = dst
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void k_multi_flatten(const int64_t* __restrict__ table, int ntensors, float scale) {
+    const Row* r;
+    long base;
+    locate(table, ntensors, blockIdx.x, r, base);
+    const S* src = reinterpret_cast<const S*>(r->p0);
+    D* dst = reinterpret_cast<D*>(r->p1);
+    const long n = r->numel;
+#pragma unroll
+    for (int it = 0; it < kMTChunk / (256 * 4); ++it) {
+        const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+        if (i >= n) break;
+        float v[4];
+        load4<S>(src, i, n, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= scale;
+        store4(dst, i, n, v);
+    }
+}
+
+// row: p0 = param (f32), p1 = grad, p2 = exp_avg, p3 = exp_avg_sq, p4 = bf16 copy or 0
+template <typename G>
+__global__ __launch_bounds__(256) void k_multi_adam(const int64_t* __restrict__ table, int ntensors, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt, int adamw, float gscale) {
+    const Row* r;
+    long base;
+    locate(table, ntensors, blockIdx.x, r, base);
+    float* p = reinterpret_cast<float*>(r->p0);
+    const G* g = reinterpret_cast<const G*>(r->p1);
+    float* m = reinterpret_cast<float*>(r->p2);
+    float* v = reinterpret_cast<float*>(r->p3);
+    bf16* lp = reinterpret_cast<bf16*>(r->p4);
+    const long n = r->numel;
+    const float step_size = lr / bc1;
+#pragma unroll
+    for (int it = 0; it < kMTChunk / (256 * 4); ++it) {
+        const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+        if (i >= n) break;
+        float pv[4], gv[4], mv[4], vv[4];
+        load4<float>(p, i, n, pv);
+        load4<G>(g, i, n, gv);
+        load4<float>(m, i, n, mv);
+        load4<float>(v, i, n, vv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gg = gv[k] * gscale;
+            float pp = pv[k];
+            if (wd != 0.f) {
+                if (adamw) pp *= (1.f - lr * wd);
+                else gg += wd * pp;
+            }
+            const float mm = beta1 * mv[k] + (1.f - beta1) * gg;
+            const float v2 = beta2 * vv[k] + (1.f - beta2) * gg * gg;
+            const float denom = sqrtf(v2) / bc2_sqrt + eps;
+            pp -= step_size * (mm / denom);
+            pv[k] = pp; mv[k] = mm; vv[k] = v2;
+        }
+        store4(p, i, n, pv);
+        store4(m, i, n, mv);
+        store4(v, i, n, vv);
+        if (lp) store4(lp, i, n, pv);
+    }
+}
+
+// row: p0 = param (f32), p1 = grad, p2 = momentum buffer (or 0), p4 = bf16 copy or 0
+template <typename G>
+__global__ __launch_bounds__(256) void k_multi_sgd(const int64_t* __restrict__ table, int ntensors, float lr,
+                                                   float momentum, float dampening, float wd, int nesterov,
+                                                   int first, float gscale) {
+    const Row* r;
+    long base;
+    locate(table, ntensors, blockIdx.x, r, base);
+    float* p = reinterpret_cast<float*>(r->p0);
+    const G* g = reinterpret_cast<const G*>(r->p1);
+    float* buf = reinterpret_cast<float*>(r->p2);
+    bf16* lp = reinterpret_cast<bf16*>(r->p4);
+    const long n = r->numel;
+#pragma unroll
+    for (int it = 0; it < kMTChunk / (256 * 4); ++it) {
+        const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+        if (i >= n) break;
+        float pv[4], gv[4], bv[4] = {0.f, 0.f, 0.f, 0.f};
+        load4<float>(p, i, n, pv);
+        load4<G>(g, i, n, gv);
+        if (momentum != 0.f && !first) load4<float>(buf, i, n, bv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gg = gv[k] * gscale + wd * pv[k];
+            if (momentum != 0.f) {
+                const float b = first ? gg : momentum * bv[k] + (1.f - dampening) * gg;
+                bv[k] = b;
+                gg = nesterov ? gg + momentum * b : b;
+            }
+            pv[k] -= lr * gg;
+        }
+        store4(p, i, n, pv);
+        if (momentum != 0.f) store4(buf, i, n, bv);
+        if (lp) store4(lp, i, n, pv);
+    }
+}
+
+// f32 NCHW -> bf16 NHWC through an LDS tile so both sides move full lines.
+// block = (b, h) row: tile [C][W] read coalesced along W, written coalesced along C.
+__global__ __launch_bounds__(256) void k_nchw_f32_to_nhwc_bf16(const float* __restrict__ src, bf16* __restrict__ dst,
+                                                               int C, int H, int W, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);  // [C][W+1]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int pitch = W + 1;
+    for (int i = threadIdx.x; i < C * W; i += blockDim.x) {
+        const int c = i / W, w = i % W;
+        tile[c * pitch + w] = src[(((long)b * C + c) * H + h) * W + w] * scale;
+    }
+    __syncthreads();
+    bf16* out = dst + ((long)b * H + h) * W * C;
+    for (int i = threadIdx.x; i < C * W; i += blockDim.x) {
+        const int w = i / C, c = i % C;
+        out[i] = (bf16)tile[c * pitch + w];
+    }
+}
+
+// u8 NHWC -> bf16 NHWC (pure elementwise)
+__global__ __launch_bounds__(256) void k_u8_to_bf16(const uint8_t* __restrict__ src, bf16* __restrict__ dst, long n,
+                                                    float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = (bf16)((float)src[i] * scale);
+}
+
+// w [N][T][C] -> wt [C][T][N]; one block per (t, 32x32 tile of (n, c))
+__global__ __launch_bounds__(256) void k_transpose_ntc(const bf16* __restrict__ w, bf16* __restrict__ wt, int N, int T,
+                                                       int C) {
+    __shared__ bf16 tile[32][34];
+    const int t = blockIdx.z;
+    const int n0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, c = c0 + tx;
+        tile[r][tx] = (n < N && c < C) ? w[((long)n * T + t) * C + c] : (bf16)0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, n = n0 + tx;
+        if (n < N && c < C) wt[((long)c * T + t) * N + n] = tile[tx][r];
+    }
+}
+
+// out[y][j] = sum over the parts of chunk y of slab[p*stride + j].  Block = 64 column quads x 4
+// part lanes; grid = (column blocks of 256, part chunks).  Deterministic (no atomics).
+__global__ __launch_bounds__(256) void k_reduce_slab(const float* __restrict__ slab, int nparts, long stride, int n,
+                                                     int parts_per_chunk, float* __restrict__ out) {
+    __shared__ float red[4][64][4];
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const long j = ((long)blockIdx.x * 64 + cq) * 4;
+    const int p0 = blockIdx.y * parts_per_chunk;
+    const int p1 = min(nparts, p0 + parts_per_chunk);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (j < n) {
+        for (int p = p0 + rl; p < p1; p += 4) {
+            float v[4];
+            load4<float>(slab + (long)p * stride, j, n, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += v[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[rl][cq][k] = a[k];
+    __syncthreads();
+    if (rl == 0 && j < n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = red[0][cq][k] + red[1][cq][k] + red[2][cq][k] + red[3][cq][k];
+        store4(out + (long)blockIdx.y * n, j, n, a);
+    }
+}
+
+}  // namespace
+
+void launch_multi_flatten(const int64_t* table, int ntensors, int nchunks, float scale, int src_dtype,
+                          int dst_dtype, hipStream_t s) {
+    if (nchunks <= 0) return;
+    dim3 grid(nchunks), block(256);
+    if (src_dtype == kF32 && dst_dtype == kF32)
+        hipLaunchKernelGGL((k_multi_flatten<float, float>), grid, block, 0, s, table, ntensors, scale);
+    else if (src_dtype == kF32 && dst_dtype == kBF16)
+        hipLaunchKernelGGL((k_multi_flatten<float, bf16>), grid, block, 0, s, table, ntensors, scale);
+    else if (src_dtype == kBF16 && dst_dtype == kF32)
+        hipLaunchKernelGGL((k_multi_flatten<bf16, float>), grid, block, 0, s, table, ntensors, scale);
+    else
+        hipLaunchKernelGGL((k_multi_flatten<bf16, bf16>), grid, block, 0, s, table, ntensors, scale);
+}
+
+void launch_multi_adam(const int64_t* table, int ntensors, int nchunks, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, float bias_corr1, float bias_corr2_sqrt, int adamw,
+                       float grad_scale, int grad_dtype, hipStream_t s) {
+    if (nchunks <= 0) return;
+    dim3 grid(nchunks), block(256);
+    if (grad_dtype == kF32)
+        hipLaunchKernelGGL((k_multi_adam<float>), grid, block, 0, s, table, ntensors, lr, beta1, beta2, eps,
+                           weight_decay, bias_corr1, bias_corr2_sqrt, adamw, grad_scale);
+    else
+        hipLaunchKernelGGL((k_multi_adam<bf16>), grid, block, 0, s, table, ntensors, lr, beta1, beta2, eps,
+                           weight_decay, bias_corr1, bias_corr2_sqrt, adamw, grad_scale);
+}
+
+void launch_multi_sgd(const int64_t* table, int ntensors, int nchunks, float lr, float momentum, float dampening,
+                      float weight_decay, int nesterov, int first, float grad_scale, int grad_dtype,
+                      hipStream_t s) {
+    if (nchunks <= 0) return;
+    dim3 grid(nchunks), block(256);
+    if (grad_dtype == kF32)
+        hipLaunchKernelGGL((k_multi_sgd<float>), grid, block, 0, s, table, ntensors, lr, momentum, dampening,
+                           weight_decay, nesterov, first, grad_scale);
+    else
+        hipLaunchKernelGGL((k_multi_sgd<bf16>), grid, block, 0, s, table, ntensors, lr, momentum, dampening,
+                           weight_decay, nesterov, first, grad_scale);
+}
+
+void launch_to_nhwc_bf16(const void* src, int src_dtype, void* dst, int B, int C, int H, int W, float scale,
+                         hipStream_t s) {
+    if (src_dtype == kF32) {
+        const size_t lds = (size_t)C * (W + 1) * sizeof(float);
+        hipLaunchKernelGGL(k_nchw_f32_to_nhwc_bf16, dim3(B * H), dim3(256), lds, s, (const float*)src, (bf16*)dst, C,
+                           H, W, scale);
+    } else {
+        const long n = (long)B * C * H * W;
+        const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k_u8_to_bf16, dim3(grid), dim3(256), 0, s, (const uint8_t*)src, (bf16*)dst, n, scale);
+    }
+}
+
+void launch_transpose_ntc(const void* w, void* wt, int N, int T, int C, hipStream_t s) {
+    dim3 grid((C + 31) / 32, (N + 31) / 32, T);
+    hipLaunchKernelGGL(k_transpose_ntc, grid, dim3(256), 0, s, (const bf16*)w, (bf16*)wt, N, T, C);
+}
+
+void launch_reduce_slab(const float* slab, int nparts, long stride, int n, float* out, float* tmp,
+                        hipStream_t s) {
+    const int colblocks = (n + 255) / 256;
+    if (nparts > 64 && tmp != nullptr) {
+        // two deterministic levels: [nparts] -> [kReduceChunks] -> 1
+        const int ppc = (nparts + kReduceChunks - 1) / kReduceChunks;
+        const int chunks = (nparts + ppc - 1) / ppc;
+        hipLaunchKernelGGL(k_reduce_slab, dim3(colblocks, chunks), dim3(256), 0, s, slab, nparts, stride, n, ppc, tmp);
+        hipLaunchKernelGGL(k_reduce_slab, dim3(colblocks, 1), dim3(256), 0, s, (const float*)tmp, chunks, (long)n, n,
+                           chunks, out);
+    } else {
+        hipLaunchKernelGGL(k_reduce_slab, dim3(colblocks, 1), dim3(256), 0, s, slab, nparts, stride, n, nparts, out);
+    }
+}
+
+}  // namespace pdt

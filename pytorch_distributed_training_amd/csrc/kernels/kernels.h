@@ -1,0 +1,92 @@
+// Host-side launchers of the gfx950 kernels.  Pure HIP (no torch headers): the bindings in
+// csrc/binding validate shapes / dtypes / alignment and pass raw pointers + the current stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pdt {
+
+enum DType : int { kF32 = 0, kBF16 = 1, kU8 = 2 };
+
+// ---- multi-tensor (device-resident table: rows of 8 x int64 per tensor, then one int64 per
+//      4096-element chunk = (tensor_index << 32) | chunk_in_tensor) ---------------------------
+constexpr int kMTChunk = 4096;
+constexpr int kMTCols = 8;
+void launch_multi_flatten(const int64_t* table, int ntensors, int nchunks, float scale, int src_dtype,
+                          int dst_dtype, hipStream_t s);
+void launch_multi_adam(const int64_t* table, int ntensors, int nchunks, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, float bias_corr1, float bias_corr2_sqrt, int adamw,
+                       float grad_scale, int grad_dtype, hipStream_t s);
+void launch_multi_sgd(const int64_t* table, int ntensors, int nchunks, float lr, float momentum, float dampening,
+                      float weight_decay, int nesterov, int first, float grad_scale, int grad_dtype,
+                      hipStream_t s);
+
+// ---- layout / cast ---------------------------------------------------------------------------
+// src: f32 NCHW (kF32) or u8 NHWC (kU8) -> dst bf16 NHWC, value * scale
+void launch_to_nhwc_bf16(const void* src, int src_dtype, void* dst, int B, int C, int H, int W, float scale,
+                         hipStream_t s);
+// w [N][T][C] -> wt [C][T][N]  (bf16)
+void launch_transpose_ntc(const void* w, void* wt, int N, int T, int C, hipStream_t s);
+// out[j] = sum_p slab[p*stride + j], j < n  (fp32, deterministic).  tmp: fp32 [kReduceChunks][n]
+// workspace, required when nparts > 64 (two-level reduction).
+constexpr int kReduceChunks = 32;
+void launch_reduce_slab(const float* slab, int nparts, long stride, int n, float* out, float* tmp, hipStream_t s);
+
+// ---- softmax cross-entropy (mean), fwd + bwd in one pass -------------------------------------
+void launch_softmax_ce(const void* logits, int dtype, const int64_t* labels, int B, int N, float* row_loss,
+                       void* dlogits, float* loss_out, hipStream_t s);
+
+// ---- batch norm (NHWC bf16, per-channel vectors fp32) ----------------------------------------
+int bn_parts(long M, int C);  // number of partial rows the stats / bwd-reduce kernels write
+void launch_bn_stats(const void* x, long M, int C, float* slab /*[parts][2][C]*/, int parts, hipStream_t s);
+// stats[2][C] + count (device scalar if count_dev != nullptr) -> mean, invstd; optional running update
+void launch_bn_finalize(const float* stats, int C, float count, const float* count_dev, float eps,
+                        float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                        hipStream_t s);
+void launch_bn_apply(const void* x, const void* residual, void* z, long M, int C, const float* mean,
+                     const float* invstd, const float* gamma, const float* beta, int relu, hipStream_t s);
+void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, int C, const float* mean,
+                          const float* invstd, int relu, float* slab /*[parts][2][C]*/, int parts,
+                          hipStream_t s);
+void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx, void* dres, long M, int C,
+                         const float* mean, const float* invstd, const float* gamma, const float* sums,
+                         float count, const float* count_dev, int relu, hipStream_t s);
+
+// ---- pools (NHWC bf16) -----------------------------------------------------------------------
+void launch_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int B, int H, int W, int C, int Ho, int Wo,
+                             hipStream_t s);
+void launch_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int H, int W, int C, int Ho,
+                             int Wo, hipStream_t s);
+void launch_global_avgpool_fwd(const void* x, void* y, int B, int HW, int C, hipStream_t s);
+void launch_global_avgpool_bwd(const void* dy, void* dx, int B, int HW, int C, hipStream_t s);
+
+// ---- implicit-GEMM convolution on MFMA --------------------------------------------------------
+constexpr int kMaxTaps = 49;
+struct ConvGeom {
+    // input tensor (activations for fwd, dY for dgrad): [B, Hin, Win, C] bf16
+    int B, Hin, Win, C;
+    // output tensor: [B, Hout, Wout, N] bf16; this launch writes pixels (i*os + ooh, j*os + oow), i<nOH, j<nOW
+    int Hout, Wout, N;
+    int nOH, nOW, os, ooh, oow;
+    int is;  // input step per output index: in_h = i*is + dh[t]
+    int ntaps;        // taps of this launch
+    int wtaps;        // T of the weight tensor [N][wtaps][C]
+    int8_t dh[kMaxTaps], dw[kMaxTaps], wslot[kMaxTaps];
+};
+// y = conv(x, w); when stats_slab != nullptr also writes per-(m-tile) partial [sum, sum_sq] rows
+// stats_slab[m_tile][2][N] computed from the bf16-rounded outputs.
+int conv_igemm_m_tiles(const ConvGeom& g, int* bm_out);
+void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab,
+                       hipStream_t s);
+
+struct WgradGeom {
+    int B, Hin, Win, C;    // x: [B,Hin,Win,C]
+    int Hout, Wout, N;     // dy: [B,Hout,Wout,N]
+    int KH, KW, stride, pad;
+    int splits;            // M-splits (slab rows)
+};
+int conv_wgrad_splits(const WgradGeom& g);
+// slab[split][N][KH*KW][C] fp32 partials (to be summed by launch_reduce_slab)
+void launch_conv_wgrad(const void* dy, const void* x, float* slab, const WgradGeom& g, hipStream_t s);
+
+}  // namespace pdt

@@ -1,0 +1,174 @@
+// ResNet stem max-pool (3x3 / stride 2 / pad 1) and the global average pool, NHWC bf16
+// (SURVEY 2.4 N9).  A thread owns 8 consecutive channels (16 B) of one output pixel.
+// Forward records the winning tap (0..8, first maximum in scan order like ATen) so backward
+// is a gather over the <= 4 windows that cover an input pixel: no atomics, deterministic.
+#include "common.h"
+#include "kernels.h"
+
+namespace pdt {
+namespace {
+
+__device__ __forceinline__ bf16x8 ld8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                     uint8_t* __restrict__ argmax, int B, int H, int W, int C, int Ho,
+                                                     int Wo) {
+    const int G = C >> 3;
+    const long total = (long)B * Ho * Wo * G;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % G);
+        long p = i / G;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float best[8];
+        uint8_t arg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            best[k] = -INFINITY;
+            arg[k] = 0;
+        }
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = ho * 2 - 1 + r;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = wo * 2 - 1 + s;
+                if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
+                const bf16x8 v = ld8(x + (((long)b * H + hi) * W + wi) * C + cg * 8);
+                const uint8_t tap = (uint8_t)(r * 3 + s);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float f = (float)v[k];
+                    if (!any) arg[k] = tap;            // ATen: index starts at the first in-bounds tap
+                    if (f > best[k] || f != f) {       // strict '>' keeps the first maximum; NaN propagates
+                        best[k] = f;
+                        arg[k] = tap;
+                    }
+                }
+                any = true;
+            }
+        }
+        const long off = (((long)b * Ho + ho) * Wo + wo) * C + cg * 8;
+        bf16x8 o;
+        uint64_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o[k] = (bf16)best[k];
+            packed |= (uint64_t)arg[k] << (8 * k);
+        }
+        *reinterpret_cast<bf16x8*>(y + off) = o;
+        *reinterpret_cast<uint64_t*>(argmax + off) = packed;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const bf16* __restrict__ dy, const uint8_t* __restrict__ argmax,
+                                                     bf16* __restrict__ dx, int B, int H, int W, int C, int Ho,
+                                                     int Wo) {
+    const int G = C >> 3;
+    const long total = (long)B * H * W * G;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % G);
+        long p = i / G;
+        const int wi = (int)(p % W);
+        p /= W;
+        const int hi = (int)(p % H);
+        const int b = (int)(p / H);
+        float acc[8] = {0};
+        // windows (ho, wo) with ho*2-1 <= hi <= ho*2+1
+        const int ho_lo = (hi) / 2, ho_hi = (hi + 1) / 2;  // hi = 2ho-1+r, r in 0..2
+        const int wo_lo = (wi) / 2, wo_hi = (wi + 1) / 2;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            if (ho < 0 || ho >= Ho) continue;
+            const int r = hi - (ho * 2 - 1);
+            if (r < 0 || r > 2) continue;
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                if (wo < 0 || wo >= Wo) continue;
+                const int s = wi - (wo * 2 - 1);
+                if (s < 0 || s > 2) continue;
+                const long off = (((long)b * Ho + ho) * Wo + wo) * C + cg * 8;
+                const bf16x8 g = ld8(dy + off);
+                const uint64_t a = *reinterpret_cast<const uint64_t*>(argmax + off);
+                const uint8_t tap = (uint8_t)(r * 3 + s);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((uint8_t)(a >> (8 * k)) == tap) acc[k] += (float)g[k];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (bf16)acc[k];
+        *reinterpret_cast<bf16x8*>(dx + (((long)b * H + hi) * W + wi) * C + cg * 8) = o;
+    }
+}
+
+// y[b][c] = mean over HW; thread = (b, 8 channels)
+__global__ __launch_bounds__(256) void k_avgpool_fwd(const bf16* __restrict__ x, bf16* __restrict__ y, int B, int HW,
+                                                     int C) {
+    const int G = C >> 3;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * G) return;
+    const int cg = (int)(i % G);
+    const int b = (int)(i / G);
+    float acc[8] = {0};
+    const bf16* p = x + (long)b * HW * C + cg * 8;
+    for (int r = 0; r < HW; ++r) {
+        const bf16x8 v = ld8(p + (long)r * C);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += (float)v[k];
+    }
+    bf16x8 o;
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (bf16)(acc[k] * inv);
+    *reinterpret_cast<bf16x8*>(y + (long)b * C + cg * 8) = o;
+}
+
+__global__ __launch_bounds__(256) void k_avgpool_bwd(const bf16* __restrict__ dy, bf16* __restrict__ dx, int B, int HW,
+                                                     int C) {
+    const int G = C >> 3;
+    const long total = (long)B * HW * G;
+    const float inv = 1.f / (float)HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % G);
+        const int b = (int)(i / ((long)HW * G));
+        const bf16x8 g = ld8(dy + (long)b * C + cg * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (bf16)((float)g[k] * inv);
+        *reinterpret_cast<bf16x8*>(dx + i * 8) = o;
+    }
+}
+
+inline int grid_cap(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+void launch_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int B, int H, int W, int C, int Ho, int Wo,
+                             hipStream_t s) {
+    const long total = (long)B * Ho * Wo * (C >> 3);
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_cap(total)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, argmax, B, H,
+                       W, C, Ho, Wo);
+}
+void launch_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int H, int W, int C, int Ho,
+                             int Wo, hipStream_t s) {
+    const long total = (long)B * H * W * (C >> 3);
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(grid_cap(total)), dim3(256), 0, s, (const bf16*)dy, argmax, (bf16*)dx, B, H,
+                       W, C, Ho, Wo);
+}
+void launch_global_avgpool_fwd(const void* x, void* y, int B, int HW, int C, hipStream_t s) {
+    const long total = (long)B * (C >> 3);
+    hipLaunchKernelGGL(k_avgpool_fwd, dim3((int)((total + 255) / 256)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, B,
+                       HW, C);
+}
+void launch_global_avgpool_bwd(const void* dy, void* dx, int B, int HW, int C, hipStream_t s) {
+    const long total = (long)B * HW * (C >> 3);
+    hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_cap(total)), dim3(256), 0, s, (const bf16*)dy, (bf16*)dx, B, HW, C);
+}
+
+}  // namespace pdt

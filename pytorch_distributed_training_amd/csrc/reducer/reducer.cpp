@@ -1,0 +1,288 @@
+#include "reducer.h"
+
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/engine.h>
+#include <torch/csrc/autograd/functions/accumulate_grad.h>
+#include <torch/csrc/autograd/utils/lambda_post_hook.h>
+#include <torch/csrc/distributed/c10d/Types.hpp>
+
+#include "../binding/binding.h"
+
+namespace pdt {
+
+namespace {
+constexpr int64_t kAlign = 128;  // elements; every slot stays 256/512-B aligned for 16 B/lane access
+int64_t pad(int64_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
+
+#define PDT_HIP(expr)                                                                \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        TORCH_CHECK(_e == hipSuccess, "HIP error: ", hipGetErrorString(_e), " (" #expr ")"); \
+    } while (0)
+}  // namespace
+
+std::vector<BucketPlan> plan_buckets(const std::vector<int64_t>& numels, const std::vector<int64_t>& order,
+                                     int64_t elem_size, int64_t cap_bytes, int64_t first_cap_bytes) {
+    std::vector<BucketPlan> out;
+    BucketPlan cur;
+    int64_t cap = first_cap_bytes > 0 ? first_cap_bytes : cap_bytes;
+    for (int64_t idx : order) {
+        const int64_t n = pad(numels[idx]);
+        if (!cur.params.empty() && (cur.numel + n) * elem_size > cap) {
+            out.push_back(std::move(cur));
+            cur = BucketPlan();
+            cap = cap_bytes;
+        }
+        cur.params.push_back(idx);
+        cur.offsets.push_back(cur.numel);
+        cur.numel += n;
+    }
+    if (!cur.params.empty()) out.push_back(std::move(cur));
+    return out;
+}
+
+Reducer::Reducer(std::vector<at::Tensor> params, std::vector<std::string> names, std::shared_ptr<RcclComm> rccl,
+                 c10::intrusive_ptr<c10d::ProcessGroup> pg, int64_t world_size, int64_t cap_bytes,
+                 int64_t first_cap_bytes, c10::optional<at::ScalarType> grad_dtype, bool gradient_as_bucket_view)
+    : params_(std::move(params)),
+      names_(std::move(names)),
+      rccl_(std::move(rccl)),
+      pg_(std::move(pg)),
+      world_(world_size),
+      cap_(cap_bytes),
+      first_cap_(first_cap_bytes),
+      as_view_(gradient_as_bucket_view) {
+    TORCH_CHECK(!params_.empty(), "Reducer: no parameters");
+    is_cuda_ = params_[0].is_cuda();
+    grad_dtype_ = grad_dtype.value_or(params_[0].scalar_type());
+    for (const auto& p : params_) {
+        TORCH_CHECK(p.device() == params_[0].device(), "Reducer: all parameters must live on one device");
+        numels_.push_back(p.numel());
+    }
+    TORCH_CHECK(world_ == 1 || rccl_ || pg_, "Reducer: world_size > 1 needs a communicator");
+    std::vector<int64_t> order;
+    for (int64_t i = (int64_t)params_.size() - 1; i >= 0; --i) order.push_back(i);
+    build(order);
+
+    // hooks on the AccumulateGrad nodes: fire after .grad has been written
+    for (size_t i = 0; i < params_.size(); ++i) {
+        if (!params_[i].requires_grad()) continue;
+        auto acc = torch::autograd::impl::grad_accumulator(params_[i]);
+        const uintptr_t key = acc->add_post_hook(std::make_unique<torch::autograd::utils::LambdaPostHook>(
+            [this, i](const torch::autograd::variable_list& outputs, const torch::autograd::variable_list&) {
+                this->on_grad_ready(i);
+                return outputs;
+            }));
+        accumulators_.push_back(std::move(acc));
+        hook_keys_.push_back(key);
+    }
+}
+
+Reducer::~Reducer() {
+    remove_hooks();
+    destroy_buckets();
+}
+
+void Reducer::remove_hooks() {
+    for (size_t k = 0; k < accumulators_.size(); ++k) accumulators_[k]->del_post_hook(hook_keys_[k]);
+    accumulators_.clear();
+    hook_keys_.clear();
+}
+
+void Reducer::destroy_buckets() {
+    for (auto& b : buckets_)
+        if (b.done) hipEventDestroy(b.done);
+    buckets_.clear();
+}
+
+void Reducer::build(const std::vector<int64_t>& order_in) {
+    std::vector<int64_t> order;
+    for (int64_t i : order_in)
+        if (params_[i].requires_grad()) order.push_back(i);
+    destroy_buckets();
+    const int64_t elem = (int64_t)c10::elementSize(grad_dtype_);
+    auto plans = plan_buckets(numels_, order, elem, cap_, first_cap_);
+    where_.assign(params_.size(), {SIZE_MAX, SIZE_MAX});
+    auto opts = params_[0].options().dtype(grad_dtype_).requires_grad(false);
+    for (size_t bi = 0; bi < plans.size(); ++bi) {
+        Bucket b;
+        b.plan = plans[bi];
+        b.flat = at::zeros({b.plan.numel}, opts);
+        for (size_t j = 0; j < b.plan.params.size(); ++j) {
+            const auto& p = params_[b.plan.params[j]];
+            at::Tensor v;
+            if (p.is_non_overlapping_and_dense())
+                v = at::as_strided(b.flat, p.sizes(), p.strides(), b.plan.offsets[j]);
+            else
+                v = b.flat.narrow(0, b.plan.offsets[j], p.numel()).view(p.sizes());
+            b.views.push_back(v);
+            where_[b.plan.params[j]] = {bi, j};
+        }
+        b.ready.assign(b.plan.params.size(), 0);
+        b.pending = (int64_t)b.plan.params.size();
+        if (is_cuda_) PDT_HIP(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+        buckets_.push_back(std::move(b));
+    }
+    order_ = order;
+}
+
+void Reducer::prepare_for_backward() {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto& b : buckets_) {
+        std::fill(b.ready.begin(), b.ready.end(), 0);
+        b.pending = (int64_t)b.plan.params.size();
+        b.launched = false;
+        b.work.reset();
+    }
+    next_bucket_ = 0;
+    callback_queued_ = false;
+    if (!rebuilt_) ready_order_.clear();
+}
+
+void Reducer::on_grad_ready(size_t idx) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!require_sync_) return;
+    if (!callback_queued_) {
+        torch::autograd::Engine::get_default_engine().queue_callback([this] { this->finalize(); });
+        callback_queued_ = true;
+    }
+    if (!rebuilt_) ready_order_.push_back((int64_t)idx);
+    const auto [bi, j] = where_[idx];
+    TORCH_CHECK(bi != SIZE_MAX, "gradient for a parameter that is not in any bucket: ", names_[idx]);
+    Bucket& b = buckets_[bi];
+    TORCH_CHECK(!b.ready[j], "parameter ", names_[idx],
+                " received a second gradient in one backward; run the DDP forward once per backward");
+    b.ready[j] = 1;
+    --b.pending;
+    launch_ready();
+}
+
+void Reducer::launch_ready() {
+    while (next_bucket_ < buckets_.size() && buckets_[next_bucket_].pending == 0) {
+        launch(buckets_[next_bucket_]);
+        ++next_bucket_;
+    }
+}
+
+void Reducer::launch(Bucket& b) {
+    const double scale = 1.0 / (double)world_;
+    std::vector<at::Tensor> srcs, dsts;
+    for (size_t j = 0; j < b.plan.params.size(); ++j) {
+        const at::Tensor& g = params_[b.plan.params[j]].grad();
+        at::Tensor& v = b.views[j];
+        if (!g.defined()) {  // unused in this graph: contributes zeros
+            v.zero_();
+            continue;
+        }
+        const bool aliased = g.data_ptr() == v.data_ptr() && g.strides() == v.strides() &&
+                             g.scalar_type() == v.scalar_type();
+        if (aliased && world_ == 1) continue;  // already in place, nothing to scale
+        if (is_cuda_ && g.is_non_overlapping_and_dense() && g.strides() == v.strides() &&
+            reinterpret_cast<uintptr_t>(g.data_ptr()) % 16 == 0 &&
+            (g.scalar_type() == at::kFloat || g.scalar_type() == at::kBFloat16)) {
+            srcs.push_back(g);
+            dsts.push_back(v);
+        } else if (aliased) {
+            v.mul_(scale);
+        } else {
+            v.copy_(g);
+            if (world_ != 1) v.mul_(scale);
+        }
+    }
+    if (!srcs.empty()) multi_flatten_tensors(srcs, dsts, scale);  // one launch: copy + 1/W (+ cast)  (N2)
+
+    if (world_ > 1) {
+        if (rccl_ && is_cuda_) {
+            hipStream_t compute = c10::hip::getCurrentHIPStream(b.flat.device().index()).stream();
+            rccl_->fence_from(compute);           // comm stream waits for the flatten
+            rccl_->all_reduce_sum(b.flat);        // overlaps the rest of backward
+            PDT_HIP(hipEventRecord(b.done, rccl_->stream()));
+        } else {
+            std::vector<at::Tensor> ts{b.flat};
+            c10d::AllreduceOptions opts;
+            opts.reduceOp = c10d::ReduceOp::SUM;
+            b.work = pg_->allreduce(ts, opts);
+        }
+    }
+    b.launched = true;
+}
+
+void Reducer::finalize() {
+    std::lock_guard<std::mutex> g(mu_);
+    callback_queued_ = false;
+    if (!require_sync_) return;
+    // parameters that never produced a gradient are zero-filled and their buckets launched now
+    while (next_bucket_ < buckets_.size()) {
+        launch(buckets_[next_bucket_]);
+        ++next_bucket_;
+    }
+    if (world_ > 1) {
+        if (rccl_ && is_cuda_) {
+            hipStream_t compute = c10::hip::getCurrentHIPStream(params_[0].device().index()).stream();
+            for (auto& b : buckets_) PDT_HIP(hipStreamWaitEvent(compute, b.done, 0));
+        } else {
+            for (auto& b : buckets_)
+                if (b.work) {
+                    b.work->wait();
+                    b.work.reset();
+                }
+        }
+    }
+    for (auto& b : buckets_) {
+        for (size_t j = 0; j < b.plan.params.size(); ++j) {
+            at::Tensor& p = params_[b.plan.params[j]];
+            at::Tensor& v = b.views[j];
+            if (as_view_ && grad_dtype_ == p.scalar_type()) {
+                const at::Tensor& cur = p.grad();
+                if (!cur.defined() || cur.data_ptr() != v.data_ptr()) p.mutable_grad() = v;
+            } else {
+                if (!p.grad().defined()) p.mutable_grad() = at::empty_like(p);
+                p.mutable_grad().copy_(v);
+            }
+        }
+    }
+    ++iteration_;
+}
+
+void Reducer::rebuild(const std::vector<int64_t>& order) {
+    std::lock_guard<std::mutex> g(mu_);
+    TORCH_CHECK(!callback_queued_, "rebuild() must be called between iterations");
+    // keep the freshly reduced gradients: re-home them into the new buckets
+    std::vector<at::Tensor> old(params_.size());
+    for (size_t i = 0; i < params_.size(); ++i)
+        if (params_[i].grad().defined()) old[i] = params_[i].grad();
+    std::vector<Bucket> keep_alive;
+    keep_alive.swap(buckets_);  // old flat buffers must outlive the copies below
+    build(order);
+    if (as_view_) {
+        for (auto& b : buckets_)
+            for (size_t j = 0; j < b.plan.params.size(); ++j) {
+                const int64_t i = b.plan.params[j];
+                if (old[i].defined() && grad_dtype_ == params_[i].scalar_type()) {
+                    b.views[j].copy_(old[i]);
+                    params_[i].mutable_grad() = b.views[j];
+                }
+            }
+    }
+    for (auto& b : keep_alive)
+        if (b.done) hipEventDestroy(b.done);
+    rebuilt_ = true;
+}
+
+std::vector<std::vector<int64_t>> Reducer::bucket_indices() const {
+    std::vector<std::vector<int64_t>> out;
+    for (const auto& b : buckets_) out.push_back(b.plan.params);
+    return out;
+}
+std::vector<int64_t> Reducer::bucket_numels() const {
+    std::vector<int64_t> out;
+    for (const auto& b : buckets_) out.push_back(b.plan.numel);
+    return out;
+}
+std::vector<at::Tensor> Reducer::bucket_tensors() const {
+    std::vector<at::Tensor> out;
+    for (const auto& b : buckets_) out.push_back(b.flat);
+    return out;
+}
+
+}  // namespace pdt

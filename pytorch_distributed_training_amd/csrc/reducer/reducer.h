@@ -1,0 +1,98 @@
+// C++ gradient reducer: the centrepiece of the data-parallel path.
+//
+//  * parameters are grouped into flat buckets (reverse registration order at first, observed
+//    gradient-ready order after iteration 1; sizes chosen for xGMI, see parallel/buckets.py);
+//  * a post hook on every parameter's AccumulateGrad node marks it ready -- no Python in the
+//    hook path (hooks run on the autograd thread without the GIL);
+//  * when every gradient of the next bucket in plan order is ready: ONE multi-tensor HIP launch
+//    copies them into the flat bucket with the 1/W scale (and an optional bf16 cast) on the
+//    compute stream, an event fences the communicator's own stream, and ncclAllReduce is
+//    enqueued there, overlapping the rest of backward;
+//  * buckets launch strictly in plan order on every rank (identical collective sequence);
+//  * the finalize callback (queued on the autograd engine) makes the compute stream wait for
+//    every bucket's completion event and points .grad at the bucket views, so the fused
+//    optimizer reads gradients straight from the flat buffers (no unflatten copy).
+// CPU tensors use the same logic with c10d (gloo) collectives: that is the plumbing/test path.
+#pragma once
+#include <ATen/ATen.h>
+#include <torch/csrc/autograd/function.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../comm/rccl_comm.h"
+
+namespace pdt {
+
+struct BucketPlan {
+    std::vector<int64_t> params;   // parameter indices
+    std::vector<int64_t> offsets;  // element offsets in the flat buffer
+    int64_t numel = 0;             // padded size
+};
+
+std::vector<BucketPlan> plan_buckets(const std::vector<int64_t>& numels, const std::vector<int64_t>& order,
+                                     int64_t elem_size, int64_t cap_bytes, int64_t first_cap_bytes);
+
+class Reducer {
+   public:
+    Reducer(std::vector<at::Tensor> params, std::vector<std::string> names, std::shared_ptr<RcclComm> rccl,
+            c10::intrusive_ptr<c10d::ProcessGroup> pg, int64_t world_size, int64_t cap_bytes, int64_t first_cap_bytes,
+            c10::optional<at::ScalarType> grad_dtype, bool gradient_as_bucket_view);
+    ~Reducer();
+
+    void prepare_for_backward();
+    void set_require_sync(bool v) { require_sync_ = v; }
+    bool rebuilt() const { return rebuilt_; }
+    int64_t iteration() const { return iteration_; }
+    std::vector<int64_t> ready_order() const { return ready_order_; }
+    std::vector<int64_t> current_order() const { return order_; }
+    void rebuild(const std::vector<int64_t>& order);  // call between iterations
+    std::vector<std::vector<int64_t>> bucket_indices() const;
+    std::vector<int64_t> bucket_numels() const;
+    std::vector<at::Tensor> bucket_tensors() const;
+    void remove_hooks();
+
+   private:
+    struct Bucket {
+        BucketPlan plan;
+        at::Tensor flat;
+        std::vector<at::Tensor> views;  // shaped like the parameters, aliasing `flat`
+        std::vector<char> ready;
+        int64_t pending = 0;
+        c10::intrusive_ptr<c10d::Work> work;
+        hipEvent_t done = nullptr;
+        bool launched = false;
+    };
+    void build(const std::vector<int64_t>& order);
+    void destroy_buckets();
+    void on_grad_ready(size_t idx);
+    void launch_ready();
+    void launch(Bucket& b);
+    void finalize();
+
+    std::vector<at::Tensor> params_;
+    std::vector<std::string> names_;
+    std::shared_ptr<RcclComm> rccl_;
+    c10::intrusive_ptr<c10d::ProcessGroup> pg_;
+    int64_t world_;
+    int64_t cap_, first_cap_;
+    at::ScalarType grad_dtype_;
+    bool as_view_;
+    bool is_cuda_;
+    bool require_sync_ = true;
+    bool rebuilt_ = false;
+    bool callback_queued_ = false;
+    int64_t iteration_ = 0;
+    size_t next_bucket_ = 0;
+    std::vector<int64_t> numels_, order_, ready_order_;
+    std::vector<Bucket> buckets_;
+    std::vector<std::pair<size_t, size_t>> where_;  // param -> (bucket, slot)
+    std::vector<std::shared_ptr<torch::autograd::Node>> accumulators_;
+    std::vector<uintptr_t> hook_keys_;
+    std::mutex mu_;
+};
+
+}  // namespace pdt

@@ -19,6 +19,7 @@ S4a/S4b).  Works on CPU tensors over gloo, which stock SyncBatchNorm refuses.
 from __future__ import annotations
 
 import collections
+import os
 
 import torch
 import torch.distributed as tdist
@@ -26,6 +27,8 @@ import torch.distributed as tdist
 from ..ops import backend_for, reference
 
 fallback_counts: collections.Counter = collections.Counter()
+# PDT_PLAIN_TORCH=1: run conv/BN/ReLU through stock PyTorch-ROCm ops (same-hardware calibration baseline)
+_PLAIN_TORCH = os.environ.get("PDT_PLAIN_TORCH", "0") == "1"
 
 
 def _note_fallback(op: str, why: str) -> None:
@@ -131,14 +134,14 @@ class _BNActFn(torch.autograd.Function):
                 stats = packed[: 2 * c].view(2, c)
                 count_t = packed[2 * c:]
             cnt = count_t if count_t is not None else count
-            mean, invstd = be.bn_finalize(stats, cnt, cfg.eps)
+            mom = 0.0
             if cfg.running_mean is not None:
                 if cfg.num_batches_tracked is not None:
                     cfg.num_batches_tracked.add_(1)
                 mom = cfg.momentum
                 if mom is None:  # cumulative moving average
                     mom = 1.0 / float(cfg.num_batches_tracked.item())
-                be.bn_update_running(cfg.running_mean, cfg.running_var, mean, invstd, cnt, mom, cfg.eps)
+            mean, invstd = be.bn_finalize(stats.float(), cnt, cfg.eps, cfg.running_mean, cfg.running_var, mom)
         else:
             mean = cfg.running_mean.float()
             invstd = torch.rsqrt(cfg.running_var.float() + cfg.eps)
@@ -189,15 +192,15 @@ class _MaxPool3x3s2Fn(torch.autograd.Function):
         if be is not reference and be.bn_unsupported_reason(x) is not None:
             _note_fallback("maxpool", "dtype/layout")
             be = reference
-        y = be.maxpool3x3s2_fwd(x)
+        y, aux = be.maxpool3x3s2_fwd(x)
         ctx.save_for_backward(x, y)
-        ctx.be = be
+        ctx.be, ctx.aux = be, aux
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y = ctx.saved_tensors
-        return ctx.be.maxpool3x3s2_bwd(_cl(dy), x, y)
+        return ctx.be.maxpool3x3s2_bwd(_cl(dy), x, y, ctx.aux)
 
 
 def maxpool3x3s2(x):
@@ -254,6 +257,18 @@ def conv_bn_act(x, conv, bn, relu: bool = True, residual=None):
     to the module's own forward.
     """
     from .modules import BatchNorm2d, Conv2d  # local: avoid cycle
+
+    if _PLAIN_TORCH:
+        # calibration mode: the same network through stock PyTorch-ROCm ops (MIOpen conv, ATen BN)
+        w = conv.weight
+        lp = getattr(w, "_lp", None)
+        w = lp if (lp is not None and lp.dtype == x.dtype) else w.to(x.dtype)
+        y = torch.nn.functional.conv2d(x, w, None, conv.stride, conv.padding)
+        y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training,
+                                           bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
 
     fusable = (
         isinstance(conv, Conv2d) and isinstance(bn, BatchNorm2d) and conv.bias is None and conv.groups == 1

@@ -1,0 +1,174 @@
+"""HIP-kernel implementations (gfx950) with the same signatures as ``ops.reference``.
+
+Every function here launches hand-written kernels from the in-tree ``_C``
+extension on the current HIP stream.  ``*_unsupported_reason`` functions say
+why a particular operand combination cannot take the native path (the caller
+then uses the library/oracle path and counts the fallback, so it shows up in
+the run summary instead of silently changing what executes).
+"""
+from __future__ import annotations
+
+import torch
+
+from ..utils.env import require_native
+from . import reference
+
+_C = require_native()
+
+_BF16 = torch.bfloat16
+
+
+# ------------------------------------------------------------------ support
+def _is_cl(t: torch.Tensor) -> bool:
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def conv_unsupported_reason(x, w, stride: int, padding: int):
+    if x.dtype != _BF16 or w.dtype != _BF16:
+        return f"dtype {x.dtype}/{w.dtype} (native conv is bf16)"
+    cout, cin, kh, kw = w.shape
+    if cin % 64 or cout % 64:
+        return f"channels {cin}->{cout} not multiples of 64"
+    if kh * kw > 49 or stride not in (1, 2):
+        return f"kernel {kh}x{kw} stride {stride}"
+    if x.numel() * 2 >= (1 << 31):
+        return "activation >= 2 GiB"
+    return None
+
+
+def bn_unsupported_reason(x):
+    if x.dtype != _BF16:
+        return f"dtype {x.dtype} (native BN/pool kernels are bf16)"
+    c = x.shape[1]
+    if c % 8 or c // 8 > 256 or 256 % (c // 8):
+        return f"channel count {c}"
+    if x.numel() * 2 >= (1 << 31):
+        return "activation >= 2 GiB"
+    return None
+
+
+def _w_cl(w):
+    return w if _is_cl(w) else w.contiguous(memory_format=torch.channels_last)
+
+
+# --------------------------------------------------------------------- conv
+def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False):
+    y, stats = _C.conv2d_fwd(x, _w_cl(w), stride, padding, want_stats)
+    return y, (stats if want_stats else None)
+
+
+def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int):
+    kh, kw = w.shape[2], w.shape[3]
+    wt = _C.transpose_weight(_w_cl(w))  # [Cin][taps][Cout]: K-contiguous operand for the dgrad GEMM
+    return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding)
+
+
+def conv2d_wgrad(dy, x, w_shape, stride: int, padding: int):
+    return _C.conv2d_wgrad(dy, x, w_shape[2], w_shape[3], stride, padding)
+
+
+# ---------------------------------------------------------------- batchnorm
+def bn_stats(x):
+    return _C.bn_stats(x)
+
+
+def _count_args(count):
+    if torch.is_tensor(count):
+        return 0.0, count.reshape(1)
+    return float(count), None
+
+
+def bn_finalize(stats, count, eps: float, running_mean=None, running_var=None, momentum: float = 0.0):
+    """mean / invstd (+ the in-place running-stat update) in ONE tiny launch, no host sync."""
+    c, cd = _count_args(count)
+    return _C.bn_finalize(stats.contiguous(), c, cd, eps, momentum, running_mean, running_var)
+
+
+def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False):
+    return _C.bn_apply_act(x, mean, invstd, gamma.contiguous(), beta.contiguous(), residual, relu)
+
+
+def bn_bwd_reduce(dz, z, x, mean, invstd, relu: bool):
+    return _C.bn_bwd_reduce(dz, z if relu else None, x, mean, invstd, relu)
+
+
+def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sums, count, relu: bool, want_dres: bool):
+    c, cd = _count_args(count)
+    dx, dres = _C.bn_bwd_elemt(dz, z if relu else None, x, mean, invstd, gamma.contiguous(),
+                               sums.contiguous().view(-1), c, cd, relu, want_dres)
+    return dx, (dres if want_dres else None)
+
+
+# -------------------------------------------------------------------- pools
+def maxpool3x3s2_fwd(x):
+    """-> (y, argmax taps as uint8 [B,Ho,Wo,C])"""
+    return _C.maxpool3x3s2_fwd(x)
+
+
+def maxpool3x3s2_bwd(dy, x, y, argmax):
+    return _C.maxpool3x3s2_bwd(dy, argmax, list(x.shape))
+
+
+def global_avgpool_fwd(x):
+    return _C.global_avgpool_fwd(x)
+
+
+def global_avgpool_bwd(dy, x_shape):
+    return _C.global_avgpool_bwd(dy, list(x_shape))
+
+
+# --------------------------------------------------------------------- loss
+def softmax_ce_fwd_bwd(logits, labels):
+    if logits.dtype not in (_BF16, torch.float32):
+        return reference.softmax_ce_fwd_bwd(logits, labels)
+    return _C.softmax_ce(logits, labels)
+
+
+# ----------------------------------------------------------- flatten / cast
+def _aligned(t):
+    return t.data_ptr() % 16 == 0 and t.is_non_overlapping_and_dense()
+
+
+def flatten_scaled_views(grads, views, scale: float):
+    fast_g, fast_v = [], []
+    for g, v in zip(grads, views):
+        if (g.is_cuda and g.dtype in (torch.float32, _BF16) and v.dtype in (torch.float32, _BF16)
+                and g.stride() == v.stride() and _aligned(g) and _aligned(v)):
+            if g.data_ptr() == v.data_ptr() and scale == 1.0:
+                continue
+            fast_g.append(g)
+            fast_v.append(v)
+        else:
+            reference.flatten_scaled_views([g], [v], scale)
+    if fast_g:
+        _C.multi_flatten(fast_g, fast_v, scale)
+
+
+def nchw_to_nhwc_lowp(x, dtype=_BF16, scale: float = 1.0):
+    if dtype != _BF16 or not x.is_contiguous() or x.dtype not in (torch.float32, torch.uint8) or (
+            x.dtype == torch.float32 and x.shape[1] * (x.shape[3] + 1) * 4 > 64 * 1024):
+        return reference.nchw_to_nhwc_lowp(x, dtype, scale)
+    return _C.to_nhwc_bf16(x, scale)
+
+
+# --------------------------------------------------------------- optimizers
+def multi_adam(params, grads, ms, vs, lps, lr, beta1, beta2, eps, weight_decay, step, adamw, grad_scale=1.0):
+    ok = all(_aligned(t) for t in (*params, *grads, *ms, *vs)) and all(lp is None or _aligned(lp) for lp in lps) \
+        and all(p.dtype == torch.float32 for p in params) and len({g.dtype for g in grads}) == 1
+    if not ok:
+        for p, g, m, v, lp in zip(params, grads, ms, vs, lps):
+            reference.adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, float(step), adamw, grad_scale, lp)
+        return
+    _C.multi_adam(list(params), list(grads), list(ms), list(vs), list(lps), lr, beta1, beta2, eps, weight_decay,
+                  int(step), bool(adamw), grad_scale)
+
+
+def multi_sgd(params, grads, bufs, lps, lr, momentum, dampening, weight_decay, nesterov, first, grad_scale=1.0):
+    ok = all(_aligned(t) for t in (*params, *grads, *bufs)) and all(lp is None or _aligned(lp) for lp in lps) \
+        and all(p.dtype == torch.float32 for p in params) and len({g.dtype for g in grads}) == 1
+    if not ok:
+        for p, g, b, lp in zip(params, grads, bufs, lps):
+            reference.sgd_step(p, g, b, lr, momentum, dampening, weight_decay, nesterov, first, grad_scale, lp)
+        return
+    _C.multi_sgd(list(params), list(grads), list(bufs), list(lps), lr, momentum, dampening, weight_decay,
+                 bool(nesterov), bool(first), grad_scale)

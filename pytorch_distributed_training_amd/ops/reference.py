@@ -43,19 +43,20 @@ def bn_stats(x):
     return torch.stack([xf.sum((0, 2, 3)), (xf * xf).sum((0, 2, 3))], 0)
 
 
-def bn_finalize(stats, count, eps: float):
-    """``[2,C]`` sums + element count -> (mean, invstd) with biased variance."""
+def bn_finalize(stats, count, eps: float, running_mean=None, running_var=None, momentum: float = 0.0):
+    """``[2,C]`` sums + element count (float or 1-element tensor) -> (mean, invstd) with the
+    biased variance; updates the running stats in place (unbiased variance, torch semantics)."""
+    if torch.is_tensor(count):
+        count = count.reshape(()).to(stats.dtype)
     mean = stats[0] / count
-    var = (stats[1] / count - mean * mean).clamp_min_(0.0)
-    return mean, torch.rsqrt(var + eps)
-
-
-def bn_update_running(running_mean, running_var, mean, invstd, count, momentum: float, eps: float):
-    """In-place running-stat update with the unbiased variance (torch semantics)."""
-    var = 1.0 / (invstd * invstd) - eps
-    unbiased = var * (count / max(count - 1.0, 1.0))
-    running_mean.mul_(1.0 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
-    running_var.mul_(1.0 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
+    var = (stats[1] / count - mean * mean).clamp_min(0.0)
+    invstd = torch.rsqrt(var + eps)
+    if running_mean is not None:
+        denom = torch.clamp(count - 1.0, min=1.0) if torch.is_tensor(count) else max(count - 1.0, 1.0)
+        unbiased = var * (count / denom)
+        running_mean.mul_(1.0 - momentum).add_(mean.to(running_mean.dtype) * momentum)
+        running_var.mul_(1.0 - momentum).add_(unbiased.to(running_var.dtype) * momentum)
+    return mean, invstd
 
 
 def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False):
@@ -82,6 +83,8 @@ def bn_bwd_reduce(dz, z, x, mean, invstd, relu: bool):
 def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sums, count, relu: bool, want_dres: bool):
     """-> ``(dx, dres)``; ``sums`` are the (globally reduced) outputs of
     ``bn_bwd_reduce`` and ``count`` the global element count per channel."""
+    if torch.is_tensor(count):
+        count = count.reshape(())
     g = dz.float()
     if relu:
         g = g * (z > 0)
@@ -94,10 +97,11 @@ def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sums, count, relu: bool, want_dr
 
 # ---------------------------------------------------------------- pools ----
 def maxpool3x3s2_fwd(x):
-    return F.max_pool2d(x, 3, 2, 1)
+    """-> (y, aux); the oracle needs no aux"""
+    return F.max_pool2d(x, 3, 2, 1), None
 
 
-def maxpool3x3s2_bwd(dy, x, y):
+def maxpool3x3s2_bwd(dy, x, y, aux=None):
     """Gradient routed to the first max in window scan order (torch semantics)."""
     with torch.enable_grad():
         xr = x.detach().float().requires_grad_(True)

@@ -1,0 +1,108 @@
+"""Python face of the C++ reducer (``csrc/reducer``) and the native RCCL communicator.
+
+The hot path (hooks, bucket flatten launch, stream fencing, ``ncclAllReduce``,
+finalize) is C++; this wrapper only does the one-time jobs that need Python
+objects: exchanging the RCCL unique id through the c10d store, and the
+hash-check + rebuild between iteration 1 and 2.
+"""
+from __future__ import annotations
+
+import itertools
+
+import torch
+import torch.distributed as tdist
+
+from ..utils.env import require_native
+from .buckets import order_hash
+
+_comm_counter = itertools.count()
+_shared_comm = {}
+
+
+def make_rccl_comm(group=None, high_priority: bool = True):
+    """Create (or reuse) the native communicator for ``group`` (default: WORLD).
+
+    Rank 0 calls ``ncclGetUniqueId`` and publishes it in the process-group store;
+    every rank then joins with ``ncclCommInitRank``.
+    """
+    C = require_native()
+    if not (tdist.is_available() and tdist.is_initialized()) or tdist.get_world_size(group) == 1:
+        return None
+    key = (id(group), high_priority)
+    if key in _shared_comm:
+        return _shared_comm[key]
+    rank, world = tdist.get_rank(group), tdist.get_world_size(group)
+    store = tdist.distributed_c10d._get_default_store()
+    name = f"pdt/rccl_uid/{next(_comm_counter)}"
+    if rank == 0:
+        store.set(name, C.RcclComm.make_unique_id())
+    uid = bytes(store.get(name))
+    comm = C.RcclComm(rank, world, uid, torch.cuda.current_device(), high_priority)
+    _shared_comm[key] = comm
+    return comm
+
+
+class NativeReducer:
+    def __init__(self, params, comm, bucket_cap_bytes: int, first_bucket_bytes: int, grad_dtype=None,
+                 gradient_as_bucket_view: bool = True, names=None, process_group=None):
+        C = require_native()
+        self.params = list(params)
+        self.comm = comm  # TorchComm: used for the one-off hash check only
+        self.world = comm.world_size
+        self.device = self.params[0].device
+        names = list(names) if names is not None else [f"param{i}" for i in range(len(self.params))]
+        self.rccl = None
+        pg = None
+        if self.world > 1:
+            if self.device.type == "cuda":
+                self.rccl = make_rccl_comm(process_group, high_priority=True)
+            else:
+                pg = process_group if process_group is not None else tdist.distributed_c10d._get_default_group()
+        self._r = C.Reducer(self.params, names, self.rccl, pg, self.world, int(bucket_cap_bytes),
+                            int(first_bucket_bytes), grad_dtype, bool(gradient_as_bucket_view))
+        self._require_sync = True
+
+    # -- same surface as PyReducer ------------------------------------------
+    @property
+    def require_sync(self) -> bool:
+        return self._require_sync
+
+    @require_sync.setter
+    def require_sync(self, v: bool) -> None:
+        self._require_sync = bool(v)
+        self._r.set_require_sync(bool(v))
+
+    @property
+    def rebuilt(self) -> bool:
+        return self._r.rebuilt
+
+    @property
+    def iteration(self) -> int:
+        return self._r.iteration
+
+    def prepare_for_backward(self) -> None:
+        if not self._r.rebuilt and self._r.iteration >= 1:
+            self._rebuild()
+        self._r.prepare_for_backward()
+
+    def _rebuild(self) -> None:
+        ready = list(self._r.ready_order())
+        seen = set(ready)
+        order = ready + [i for i in self._r.current_order() if i not in seen]
+        hashes = self.comm.all_gather_i64(order_hash(order), self.device)
+        if len(set(hashes)) != 1:  # ranks disagree (non-deterministic graph): adopt rank 0's order
+            t = torch.tensor(order, dtype=torch.int64, device=self.device)
+            self.comm.broadcast(t, 0)
+            order = [int(v) for v in t.tolist()]
+        self._r.rebuild(order)
+
+    def bucket_specs(self):
+        from .buckets import BucketSpec
+
+        return [BucketSpec(list(idx), [], n) for idx, n in zip(self._r.bucket_indices(), self._r.bucket_numels())]
+
+    def bucket_tensors(self):
+        return self._r.bucket_tensors()
+
+    def remove_hooks(self) -> None:
+        self._r.remove_hooks()
