@@ -1,5 +1,5 @@
 // Python module `pytorch_distributed_training_amd._C`: ops, native RCCL communicator, reducer.
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
 
 #include "../comm/rccl_comm.h"
@@ -25,25 +25,25 @@ PYBIND11_MODULE(_C, m) {
         .def("stream_handle", [](pdt::RcclComm& c) { return reinterpret_cast<uintptr_t>(c.stream()); })
         // synchronous-with-the-current-stream convenience collectives (tests, broadcasts)
         .def("all_reduce_", [](pdt::RcclComm& c, at::Tensor t) {
-                 hipStream_t cur = c10::hip::getCurrentHIPStream(t.device().index()).stream();
+                 hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
                  c.fence_from(cur);
                  c.all_reduce_sum(t);
                  c.fence_to(cur);
              }, py::call_guard<py::gil_scoped_release>())
         .def("broadcast_", [](pdt::RcclComm& c, at::Tensor t, int root) {
-                 hipStream_t cur = c10::hip::getCurrentHIPStream(t.device().index()).stream();
+                 hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
                  c.fence_from(cur);
                  c.broadcast(t, root);
                  c.fence_to(cur);
              }, py::call_guard<py::gil_scoped_release>())
         .def("reduce_", [](pdt::RcclComm& c, at::Tensor t, int root) {
-                 hipStream_t cur = c10::hip::getCurrentHIPStream(t.device().index()).stream();
+                 hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
                  c.fence_from(cur);
                  c.reduce_sum(t, root);
                  c.fence_to(cur);
              }, py::call_guard<py::gil_scoped_release>())
         .def("all_gather_", [](pdt::RcclComm& c, at::Tensor src, at::Tensor dst) {
-                 hipStream_t cur = c10::hip::getCurrentHIPStream(src.device().index()).stream();
+                 hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(src.device().index()).stream();
                  c.fence_from(cur);
                  c.all_gather(src, dst);
                  c.fence_to(cur);

@@ -2,8 +2,8 @@
 // take the whole node down, so every shape / dtype / layout / size assumption of a kernel is
 // checked here), allocate outputs through the caching allocator, launch on the current stream.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
 
 #include <cmath>
@@ -19,7 +19,7 @@ namespace {
 
 using at::Tensor;
 
-hipStream_t cur_stream(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+hipStream_t cur_stream(const Tensor& t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 void check_nhwc_bf16(const Tensor& t, const char* name) {
     TORCH_CHECK(t.is_cuda(), name, ": expected a GPU tensor");
@@ -70,7 +70,7 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
     TORCH_CHECK(KH * KW <= kMaxTaps && stride >= 1 && pad >= 0 && pad < 64, "unsupported kernel geometry");
     const long Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     TORCH_CHECK(Ho > 0 && Wo > 0, "empty output");
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor y = empty_nhwc(B, N, Ho, Wo, x);
     TORCH_CHECK((long)y.numel() * 2 < (1L << 31), "output exceeds 2 GiB");
     ConvGeom g;
@@ -110,7 +110,7 @@ Tensor conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_s
     TORCH_CHECK(C % 64 == 0 && N % 64 == 0, "conv2d_dgrad: channels must be multiples of 64");
     TORCH_CHECK(stride == 1 || stride == 2, "conv2d_dgrad: stride must be 1 or 2");
     TORCH_CHECK(KH * KW <= kMaxTaps && pad < 64, "unsupported kernel geometry");
-    c10::hip::HIPGuard guard(dy.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dy.device());
     hipStream_t s = cur_stream(dy);
 
     auto base_geom = [&]() {
@@ -159,8 +159,8 @@ Tensor conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_s
             if (nt == 0) { need_zero = true; continue; }
             launches.push_back(g);
         }
-    Tensor dx = need_zero ? at::zeros({B, C, H, W}, dy.options().memory_format(at::MemoryFormat::ChannelsLast))
-                          : empty_nhwc(B, C, H, W, dy);
+    Tensor dx = empty_nhwc(B, C, H, W, dy);  // (at::zeros would drop the channels_last request)
+    if (need_zero) dx.zero_();
     TORCH_CHECK((long)dx.numel() * 2 < (1L << 31), "dx exceeds 2 GiB");
     for (const auto& g : launches) launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, nullptr, s);
     return dx;
@@ -175,7 +175,7 @@ Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, i
     TORCH_CHECK(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1, "wgrad geometry mismatch");
     TORCH_CHECK(C % 64 == 0 && N % 64 == 0, "conv2d_wgrad: channels must be multiples of 64");
     TORCH_CHECK((long)B * Ho * Wo < (1L << 31), "too many output pixels");
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     WgradGeom g{(int)B, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, (int)N, (int)KH, (int)KW, (int)stride, (int)pad, 1};
     g.splits = conv_wgrad_splits(g);
     const long wsize = N * KH * KW * C;
@@ -189,7 +189,7 @@ Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, i
 Tensor transpose_weight(const Tensor& w) {
     check_conv_weight(w, "w");
     const long N = w.size(0), C = w.size(1), T = w.size(2) * w.size(3);
-    c10::hip::HIPGuard guard(w.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(w.device());
     Tensor wt = at::empty({C, T, N}, w.options().memory_format(at::MemoryFormat::Contiguous));
     launch_transpose_ntc(w.data_ptr(), wt.data_ptr(), (int)N, (int)T, (int)C, cur_stream(w));
     return wt;
@@ -200,7 +200,7 @@ Tensor bn_stats(const Tensor& x) {
     check_nhwc_bf16(x, "x");
     const long C = x.size(1), M = x.numel() / C;
     TORCH_CHECK(bn_channels_ok(C), "bn: unsupported channel count ", C);
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     const int parts = bn_parts(M, (int)C);
     Tensor slab = at::empty({parts, 2 * C}, x.options().dtype(at::kFloat));
     launch_bn_stats(x.data_ptr(), M, (int)C, slab.data_ptr<float>(), parts, cur_stream(x));
@@ -214,7 +214,7 @@ std::tuple<Tensor, Tensor> bn_finalize(const Tensor& stats, double count, const 
                     stats.is_contiguous(),
                 "stats: expected contiguous fp32 [2, C]");
     const long C = stats.size(1);
-    c10::hip::HIPGuard guard(stats.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(stats.device());
     Tensor mean = at::empty({C}, stats.options()), invstd = at::empty({C}, stats.options());
     float *rm = nullptr, *rv = nullptr;
     if (running_mean.has_value() && running_mean->defined()) {
@@ -247,7 +247,7 @@ Tensor bn_apply_act(const Tensor& x, const Tensor& mean, const Tensor& invstd, c
         TORCH_CHECK(residual->sizes() == x.sizes(), "residual shape mismatch");
         res = residual->data_ptr();
     }
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor z = at::empty_like(x);
     launch_bn_apply(x.data_ptr(), res, z.data_ptr(), M, (int)C, mean.data_ptr<float>(), invstd.data_ptr<float>(),
                     gamma.data_ptr<float>(), beta.data_ptr<float>(), relu ? 1 : 0, cur_stream(x));
@@ -268,7 +268,7 @@ Tensor bn_bwd_reduce(const Tensor& dz, const c10::optional<Tensor>& z, const Ten
         TORCH_CHECK(z->sizes() == x.sizes(), "z shape mismatch");
         zp = z->data_ptr();
     }
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     const int parts = bn_parts(M, (int)C);
     Tensor slab = at::empty({parts, 2 * C}, x.options().dtype(at::kFloat));
     launch_bn_bwd_reduce(dz.data_ptr(), zp, x.data_ptr(), M, (int)C, mean.data_ptr<float>(), invstd.data_ptr<float>(),
@@ -299,7 +299,7 @@ std::tuple<Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::optional<Te
                     "count_dev: expected a 1-element fp32 GPU tensor");
         cd = count_dev->data_ptr<float>();
     }
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor dx = at::empty_like(x), dres;
     void* drp = nullptr;
     if (want_dres) {
@@ -318,7 +318,7 @@ std::tuple<Tensor, Tensor> maxpool3x3s2_fwd(const Tensor& x) {
     const long B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
     TORCH_CHECK(C % 8 == 0, "maxpool: C must be a multiple of 8");
     const long Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor y = empty_nhwc(B, C, Ho, Wo, x);
     Tensor arg = at::empty({B, Ho, Wo, C}, x.options().dtype(at::kByte));
     launch_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), arg.data_ptr<uint8_t>(), B, H, W, C, Ho, Wo, cur_stream(x));
@@ -331,7 +331,7 @@ Tensor maxpool3x3s2_bwd(const Tensor& dy, const Tensor& arg, std::vector<int64_t
     TORCH_CHECK(dy.size(0) == B && dy.size(1) == C && Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "maxpool bwd shape mismatch");
     TORCH_CHECK(arg.is_cuda() && arg.scalar_type() == at::kByte && arg.is_contiguous() && arg.numel() == dy.numel(),
                 "argmax tensor mismatch");
-    c10::hip::HIPGuard guard(dy.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dy.device());
     Tensor dx = empty_nhwc(B, C, H, W, dy);
     launch_maxpool3x3s2_bwd(dy.data_ptr(), arg.data_ptr<uint8_t>(), dx.data_ptr(), B, H, W, C, Ho, Wo, cur_stream(dy));
     return dx;
@@ -340,7 +340,7 @@ Tensor global_avgpool_fwd(const Tensor& x) {
     check_nhwc_bf16(x, "x");
     const long B = x.size(0), C = x.size(1), HW = x.size(2) * x.size(3);
     TORCH_CHECK(C % 8 == 0, "avgpool: C must be a multiple of 8");
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor y = at::empty({B, C}, x.options().memory_format(at::MemoryFormat::Contiguous));
     launch_global_avgpool_fwd(x.data_ptr(), y.data_ptr(), B, HW, C, cur_stream(x));
     return y;
@@ -349,7 +349,7 @@ Tensor global_avgpool_bwd(const Tensor& dy, std::vector<int64_t> x_shape) {
     TORCH_CHECK(dy.is_cuda() && dy.scalar_type() == at::kBFloat16 && dy.dim() == 2 && dy.is_contiguous(), "dy: expected contiguous bf16 [B,C]");
     const long B = x_shape[0], C = x_shape[1], H = x_shape[2], W = x_shape[3];
     TORCH_CHECK(dy.size(0) == B && dy.size(1) == C && C % 8 == 0, "avgpool bwd shape mismatch");
-    c10::hip::HIPGuard guard(dy.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dy.device());
     Tensor dx = empty_nhwc(B, C, H, W, dy);
     launch_global_avgpool_bwd(dy.data_ptr(), dx.data_ptr(), B, H * W, C, cur_stream(dy));
     return dx;
@@ -363,7 +363,7 @@ std::tuple<Tensor, Tensor> softmax_ce(const Tensor& logits, const Tensor& labels
                     labels.numel() == logits.size(0),
                 "labels: expected contiguous int64 GPU [B]");
     const long B = logits.size(0), N = logits.size(1);
-    c10::hip::HIPGuard guard(logits.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(logits.device());
     Tensor dlogits = at::empty_like(logits);
     Tensor row_loss = at::empty({B}, logits.options().dtype(at::kFloat));
     Tensor loss = at::empty({}, logits.options().dtype(at::kFloat));
@@ -376,7 +376,7 @@ std::tuple<Tensor, Tensor> softmax_ce(const Tensor& logits, const Tensor& labels
 // ------------------------------------------------------------------------------------- cast
 Tensor to_nhwc_bf16(const Tensor& x, double scale) {
     TORCH_CHECK(x.is_cuda() && x.dim() == 4 && x.is_contiguous(), "x: expected contiguous 4-D GPU tensor");
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     if (x.scalar_type() == at::kFloat) {  // NCHW fp32
         const long B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
         TORCH_CHECK((size_t)C * (W + 1) * 4 <= 64 * 1024, "to_nhwc_bf16: C*W too large for the LDS tile");
@@ -472,7 +472,7 @@ void multi_flatten(std::vector<Tensor> srcs, std::vector<Tensor> dsts, double sc
         cols[1].push_back(&dsts[i]);
         numels.push_back(srcs[i].numel());
     }
-    c10::hip::HIPGuard guard(srcs[0].device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(srcs[0].device());
     const Table& t = get_table(cols, numels, srcs[0].device());
     launch_multi_flatten(t.dev.data_ptr<int64_t>(), t.ntensors, t.nchunks, (float)scale, dtype_code(sst),
                          dtype_code(dst_t), cur_stream(srcs[0]));
@@ -518,7 +518,7 @@ void multi_adam(std::vector<Tensor> ps, std::vector<Tensor> gs, std::vector<Tens
     std::vector<std::vector<const Tensor*>> cols;
     std::vector<int64_t> numels;
     fill_cols(ps, gs, &ms, &vs, lps, cols, numels);
-    c10::hip::HIPGuard guard(ps[0].device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(ps[0].device());
     const Table& t = get_table(cols, numels, ps[0].device());
     const double bc1 = 1.0 - std::pow(beta1, (double)step);
     const double bc2 = 1.0 - std::pow(beta2, (double)step);
@@ -534,7 +534,7 @@ void multi_sgd(std::vector<Tensor> ps, std::vector<Tensor> gs, std::vector<Tenso
     std::vector<std::vector<const Tensor*>> cols;
     std::vector<int64_t> numels;
     fill_cols(ps, gs, &bufs, nullptr, lps, cols, numels);
-    c10::hip::HIPGuard guard(ps[0].device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(ps[0].device());
     const Table& t = get_table(cols, numels, ps[0].device());
     launch_multi_sgd(t.dev.data_ptr<int64_t>(), t.ntensors, t.nchunks, (float)lr, (float)momentum, (float)dampening,
                      (float)weight_decay, nesterov ? 1 : 0, first ? 1 : 0, (float)grad_scale,

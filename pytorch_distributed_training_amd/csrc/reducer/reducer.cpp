@@ -1,6 +1,6 @@
 #include "reducer.h"
 
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/csrc/autograd/engine.h>
 #include <torch/csrc/autograd/functions/accumulate_grad.h>
 #include <torch/csrc/autograd/utils/lambda_post_hook.h>
@@ -193,7 +193,7 @@ void Reducer::launch(Bucket& b) {
 
     if (world_ > 1) {
         if (rccl_ && is_cuda_) {
-            hipStream_t compute = c10::hip::getCurrentHIPStream(b.flat.device().index()).stream();
+            hipStream_t compute = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(b.flat.device().index()).stream();
             rccl_->fence_from(compute);           // comm stream waits for the flatten
             rccl_->all_reduce_sum(b.flat);        // overlaps the rest of backward
             PDT_HIP(hipEventRecord(b.done, rccl_->stream()));
@@ -218,7 +218,7 @@ void Reducer::finalize() {
     }
     if (world_ > 1) {
         if (rccl_ && is_cuda_) {
-            hipStream_t compute = c10::hip::getCurrentHIPStream(params_[0].device().index()).stream();
+            hipStream_t compute = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(params_[0].device().index()).stream();
             for (auto& b : buckets_) PDT_HIP(hipStreamWaitEvent(compute, b.done, 0));
         } else {
             for (auto& b : buckets_)

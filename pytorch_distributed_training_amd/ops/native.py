@@ -126,7 +126,8 @@ def softmax_ce_fwd_bwd(logits, labels):
 
 # ----------------------------------------------------------- flatten / cast
 def _aligned(t):
-    return t.data_ptr() % 16 == 0 and t.is_non_overlapping_and_dense()
+    dense = t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+    return dense and t.data_ptr() % 16 == 0
 
 
 def flatten_scaled_views(grads, views, scale: float):
