@@ -78,11 +78,17 @@ def conv_cases(quick):
     ]
     if not quick:
         cases += [
-            (32, 64, 56, 56, 64, 3, 1, 1),
-            (32, 256, 56, 56, 128, 1, 1, 0),
-            (32, 128, 56, 56, 128, 3, 2, 1),
-            (32, 1024, 14, 14, 2048, 1, 2, 0),
-            (32, 512, 7, 7, 2048, 1, 1, 0),
+            (128, 64, 56, 56, 64, 3, 1, 1),
+            (128, 64, 56, 56, 256, 1, 1, 0),
+            (128, 256, 56, 56, 64, 1, 1, 0),
+            (128, 128, 28, 28, 128, 3, 1, 1),
+            (128, 512, 28, 28, 128, 1, 1, 0),
+            (128, 128, 56, 56, 128, 3, 2, 1),
+            (128, 256, 14, 14, 256, 3, 1, 1),
+            (128, 256, 14, 14, 1024, 1, 1, 0),
+            (128, 1024, 14, 14, 2048, 1, 2, 0),
+            (128, 512, 7, 7, 512, 3, 1, 1),
+            (128, 512, 7, 7, 2048, 1, 1, 0),
         ]
     return cases
 
@@ -98,8 +104,8 @@ def check_conv(args, time_it):
         y, st = native.conv2d_fwd(x, w, s, p, True)
         yr, _ = reference.conv2d_fwd(x.float(), w.float(), s, p, False)
         e = rel_err(y, yr)
-        str_ = reference.bn_stats(y)
-        es = rel_err(st, str_)
+        str_ = reference.bn_stats(y)[0]
+        es = rel_err(reference.bn_sum_partials(st), str_)
         extra = {"stats_err": es}
         if time_it:
             us = timeit(lambda: native.conv2d_fwd(x, w, s, p, True))
@@ -152,8 +158,8 @@ def check_bn(B, C, H, W, time_it):
     count = float(B * H * W)
 
     def stats():
-        st = native.bn_stats(x)
-        e = rel_err(st, reference.bn_stats(x))
+        st = native.bn_sum_partials(native.bn_stats(x))
+        e = rel_err(st, reference.bn_stats(x)[0])
         extra = {"us": round(timeit(lambda: native.bn_stats(x)), 1)} if time_it else None
         record(f"bn_stats   {tag}", e < 1e-3, e, extra)
 
@@ -161,9 +167,10 @@ def check_bn(B, C, H, W, time_it):
         st = reference.bn_stats(x)
         rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
         rm2, rv2 = rm.clone(), rv.clone()
-        mean, invstd = native.bn_finalize(st, count, 1e-5, rm, rv, 0.1)
-        mr, ir = reference.bn_finalize(st, count, 1e-5, rm2, rv2, 0.1)
-        e = max(rel_err(mean, mr), rel_err(invstd, ir), rel_err(rm, rm2), rel_err(rv, rv2))
+        nbt, nbt2 = torch.zeros((), dtype=torch.int64, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+        mean, invstd = native.bn_finalize(native.bn_stats(x), count, 1e-5, rm, rv, 0.1, nbt)
+        mr, ir = reference.bn_finalize(st, count, 1e-5, rm2, rv2, 0.1, nbt2)
+        e = max(rel_err(mean, mr), rel_err(invstd, ir), rel_err(rm, rm2), rel_err(rv, rv2), float(abs(int(nbt) - int(nbt2))))
         record(f"bn_finalize {tag}", e < 1e-4, e)
         for relu, use_res in ((True, True), (True, False), (False, False), (False, True)):
             z = native.bn_apply_act(x, mr, ir, gamma, beta, res if use_res else None, relu)
@@ -181,15 +188,15 @@ def check_bn(B, C, H, W, time_it):
         z = reference.bn_apply_act(x, mean, invstd, gamma, beta, res, True)
         dz = nhwc(B, C, H, W)
         for relu in (True, False):
-            sums = native.bn_bwd_reduce(dz, z, x, mean, invstd, relu)
+            ps = native.bn_bwd_reduce(dz, z, x, mean, invstd, relu)
             sr = reference.bn_bwd_reduce(dz, z, x, mean, invstd, relu)
-            e = rel_err(sums, sr)
+            e = rel_err(native.bn_sum_partials(ps), sr[0])
             extra = {"us": round(timeit(lambda: native.bn_bwd_reduce(dz, z, x, mean, invstd, relu)), 1)} if time_it else None
             record(f"bn_bwd_reduce r{int(relu)} {tag}", e < 2e-3, e, extra)
             for dres in (True, False):
-                dx, dr = native.bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sr, count, relu, dres)
-                dxr, drr = reference.bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sr, count, relu, dres)
-                e = rel_err(dx, dxr)
+                dx, dr, sm = native.bn_bwd_elemt(dz, z, x, mean, invstd, gamma, ps, count, relu, dres)
+                dxr, drr, smr = reference.bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sr, count, relu, dres)
+                e = max(rel_err(dx, dxr), rel_err(sm, smr))
                 if dres:
                     e = max(e, rel_err(dr, drr))
                 record(f"bn_bwd_elemt r{int(relu)} dres{int(dres)} {tag}", e < 1e-2, e)
@@ -260,8 +267,9 @@ def check_optim(time_it):
                 native.multi_sgd(ps, gs, bufs, lps, 0.1, 0.9, 0.0, 1e-4, False, step == 1)
                 for p, gg, b, lp in zip(ps_r, gs, bufs_r, lps_r):
                     reference.sgd_step(p, gg, b, 0.1, 0.9, 0.0, 1e-4, False, step == 1, 1.0, lp)
-        e = max(max(rel_err(a, b) for a, b in zip(ps, ps_r)), max(rel_err(a, b) for a, b in zip(lps, lps_r)))
-        record(f"multi_{kind}", e < 1e-5, e)
+        e = max(rel_err(a, b) for a, b in zip(ps, ps_r))
+        e_lp = max(rel_err(a, b) for a, b in zip(lps, lps_r))  # bf16 copies: may differ by one rounding step
+        record(f"multi_{kind}", e < 1e-5 and e_lp < 1e-2, e, {"lp_err": e_lp})
     run_case("multi_adam", lambda: run("adam"))
     run_case("multi_sgd", lambda: run("sgd"))
 
@@ -307,7 +315,7 @@ def main():
     if only is None or "bn" in only:
         shapes = [(4, 64, 8, 8), (3, 256, 7, 5), (2, 2048, 3, 3), (5, 128, 9, 9)]
         if not a.quick:
-            shapes += [(64, 64, 56, 56), (64, 256, 56, 56), (64, 2048, 7, 7)]
+            shapes += [(128, 64, 56, 56), (128, 256, 56, 56), (128, 512, 28, 28), (128, 2048, 7, 7)]
         for s in shapes:
             check_bn(*s, a.time)
     if only is None or "conv" in only:

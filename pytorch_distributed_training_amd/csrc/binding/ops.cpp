@@ -44,12 +44,24 @@ Tensor reduce_slab(const Tensor& slab, int nparts, long n) {
     Tensor out = at::empty({n}, slab.options());
     Tensor tmp;
     float* tmp_ptr = nullptr;
-    if (nparts > 64) {
+    // two levels only when the output is too narrow to fill the chip with column blocks
+    if (nparts > 64 && n < 64 * 256) {
         tmp = at::empty({kReduceChunks, n}, slab.options());
         tmp_ptr = tmp.data_ptr<float>();
     }
     launch_reduce_slab(slab.data_ptr<float>(), nparts, n, (int)n, out.data_ptr<float>(), tmp_ptr, cur_stream(slab));
     return out;
+}
+
+constexpr int kMaxFinalizeRows = 512;  // rows the consumer kernels (bn_finalize) sum themselves
+
+// [nparts][n] -> [<= max_rows][n]: first reduction level only (the consumer kernel fuses the second)
+Tensor shrink_rows(const Tensor& slab, int nparts, long n, int max_rows) {
+    if (nparts <= max_rows) return slab;
+    Tensor out = at::empty({kReduceChunks, n}, slab.options());
+    const int rows = launch_reduce_rows_l1(slab.data_ptr<float>(), nparts, n, (int)n, out.data_ptr<float>(),
+                                           cur_stream(slab));
+    return out.narrow(0, 0, rows);
 }
 
 // ------------------------------------------------------------------------------------- conv
@@ -92,7 +104,7 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
         slab_ptr = slab.data_ptr<float>();
     }
     launch_conv_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), g, slab_ptr, cur_stream(x));
-    if (want_stats) stats = reduce_slab(slab, m_tiles, 2 * N).view({2, N});
+    if (want_stats) stats = shrink_rows(slab, m_tiles, 2 * N, kMaxFinalizeRows).view({-1, 2, N});
     return {y, stats};
 }
 
@@ -204,16 +216,30 @@ Tensor bn_stats(const Tensor& x) {
     const int parts = bn_parts(M, (int)C);
     Tensor slab = at::empty({parts, 2 * C}, x.options().dtype(at::kFloat));
     launch_bn_stats(x.data_ptr(), M, (int)C, slab.data_ptr<float>(), parts, cur_stream(x));
-    return reduce_slab(slab, parts, 2 * C).view({2, C});
+    return slab.view({parts, 2, C});
 }
 
+void check_partials(const Tensor& stats, const char* name) {
+    TORCH_CHECK(stats.is_cuda() && stats.scalar_type() == at::kFloat && stats.dim() == 3 && stats.size(1) == 2 &&
+                    stats.is_contiguous() && stats.size(0) >= 1 && stats.size(0) <= kMaxFinalizeRows,
+                name, ": expected contiguous fp32 [P<=512, 2, C]");
+}
+const float* count_ptr(const c10::optional<Tensor>& count_dev) {
+    if (count_dev.has_value() && count_dev->defined()) {
+        TORCH_CHECK(count_dev->is_cuda() && count_dev->scalar_type() == at::kFloat && count_dev->numel() == 1,
+                    "count_dev: expected a 1-element fp32 GPU tensor");
+        return count_dev->data_ptr<float>();
+    }
+    return nullptr;
+}
+
+// stats: partial rows [P,2,C]
 std::tuple<Tensor, Tensor> bn_finalize(const Tensor& stats, double count, const c10::optional<Tensor>& count_dev,
                                        double eps, double momentum, const c10::optional<Tensor>& running_mean,
-                                       const c10::optional<Tensor>& running_var) {
-    TORCH_CHECK(stats.is_cuda() && stats.scalar_type() == at::kFloat && stats.dim() == 2 && stats.size(0) == 2 &&
-                    stats.is_contiguous(),
-                "stats: expected contiguous fp32 [2, C]");
-    const long C = stats.size(1);
+                                       const c10::optional<Tensor>& running_var,
+                                       const c10::optional<Tensor>& num_batches_tracked) {
+    check_partials(stats, "stats");
+    const long P = stats.size(0), C = stats.size(2);
     c10::hip::HIPGuardMasqueradingAsCUDA guard(stats.device());
     Tensor mean = at::empty({C}, stats.options()), invstd = at::empty({C}, stats.options());
     float *rm = nullptr, *rv = nullptr;
@@ -223,15 +249,28 @@ std::tuple<Tensor, Tensor> bn_finalize(const Tensor& stats, double count, const 
         rm = running_mean->data_ptr<float>();
         rv = running_var->data_ptr<float>();
     }
-    const float* cd = nullptr;
-    if (count_dev.has_value() && count_dev->defined()) {
-        TORCH_CHECK(count_dev->is_cuda() && count_dev->scalar_type() == at::kFloat && count_dev->numel() == 1,
-                    "count_dev: expected a 1-element fp32 GPU tensor");
-        cd = count_dev->data_ptr<float>();
+    long* nbt = nullptr;
+    if (num_batches_tracked.has_value() && num_batches_tracked->defined()) {
+        TORCH_CHECK(num_batches_tracked->is_cuda() && num_batches_tracked->scalar_type() == at::kLong &&
+                        num_batches_tracked->numel() == 1,
+                    "num_batches_tracked: expected a 1-element int64 GPU tensor");
+        nbt = reinterpret_cast<long*>(num_batches_tracked->data_ptr<int64_t>());
     }
-    launch_bn_finalize(stats.data_ptr<float>(), (int)C, (float)count, cd, (float)eps, (float)momentum, rm, rv,
-                       mean.data_ptr<float>(), invstd.data_ptr<float>(), cur_stream(stats));
+    launch_bn_finalize(stats.data_ptr<float>(), (int)P, (int)C, (float)count, count_ptr(count_dev), (float)eps,
+                       (float)momentum, rm, rv, nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(), nullptr,
+                       cur_stream(stats));
     return {mean, invstd};
+}
+
+// partial rows [P,2,C] -> [2,C] (SyncBN needs the local sums before the all-reduce)
+Tensor bn_sum_partials(const Tensor& stats) {
+    check_partials(stats, "stats");
+    const long P = stats.size(0), C = stats.size(2);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(stats.device());
+    Tensor out = at::empty({2, C}, stats.options());
+    launch_bn_finalize(stats.data_ptr<float>(), (int)P, (int)C, 1.f, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, out.data_ptr<float>(), cur_stream(stats));
+    return out;
 }
 
 Tensor bn_apply_act(const Tensor& x, const Tensor& mean, const Tensor& invstd, const Tensor& gamma, const Tensor& beta,
@@ -273,19 +312,23 @@ Tensor bn_bwd_reduce(const Tensor& dz, const c10::optional<Tensor>& z, const Ten
     Tensor slab = at::empty({parts, 2 * C}, x.options().dtype(at::kFloat));
     launch_bn_bwd_reduce(dz.data_ptr(), zp, x.data_ptr(), M, (int)C, mean.data_ptr<float>(), invstd.data_ptr<float>(),
                          relu ? 1 : 0, slab.data_ptr<float>(), parts, cur_stream(x));
-    return reduce_slab(slab, parts, 2 * C).view({2, C});
+    return shrink_rows(slab, parts, 2 * C, kReduceChunks).view({-1, 2, C});
 }
 
-std::tuple<Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::optional<Tensor>& z, const Tensor& x,
-                                        const Tensor& mean, const Tensor& invstd, const Tensor& gamma,
-                                        const Tensor& sums, double count, const c10::optional<Tensor>& count_dev,
-                                        bool relu, bool want_dres) {
+// psums: partial rows [P<=32,2,C] of bn_bwd_reduce (or [1,2,C] globally reduced sums); returns the
+// summed [2,C] as third output (local affine gradients)
+std::tuple<Tensor, Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::optional<Tensor>& z, const Tensor& x,
+                                                const Tensor& mean, const Tensor& invstd, const Tensor& gamma,
+                                                const Tensor& psums, double count,
+                                                const c10::optional<Tensor>& count_dev, bool relu, bool want_dres) {
     check_nhwc_bf16(dz, "dz"); check_nhwc_bf16(x, "x");
     TORCH_CHECK(dz.sizes() == x.sizes(), "dz/x shape mismatch");
     const long C = x.size(1), M = x.numel() / C;
     TORCH_CHECK(bn_channels_ok(C), "bn: unsupported channel count ", C);
     check_vec_f32(mean, C, "mean"); check_vec_f32(invstd, C, "invstd"); check_vec_f32(gamma, C, "gamma");
-    check_vec_f32(sums, 2 * C, "sums");
+    check_partials(psums, "psums");
+    TORCH_CHECK(psums.size(0) <= kReduceChunks && psums.size(2) == C, "psums: expected [P<=32, 2, C]");
+    TORCH_CHECK(reinterpret_cast<uintptr_t>(psums.data_ptr()) % 16 == 0 && C % 4 == 0, "psums alignment");
     const void* zp = nullptr;
     if (relu) {
         TORCH_CHECK(z.has_value() && z->defined(), "relu=True needs the forward output z");
@@ -293,23 +336,18 @@ std::tuple<Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::optional<Te
         TORCH_CHECK(z->sizes() == x.sizes(), "z shape mismatch");
         zp = z->data_ptr();
     }
-    const float* cd = nullptr;
-    if (count_dev.has_value() && count_dev->defined()) {
-        TORCH_CHECK(count_dev->is_cuda() && count_dev->scalar_type() == at::kFloat && count_dev->numel() == 1,
-                    "count_dev: expected a 1-element fp32 GPU tensor");
-        cd = count_dev->data_ptr<float>();
-    }
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor dx = at::empty_like(x), dres;
+    Tensor sums = at::empty({2, C}, psums.options());
     void* drp = nullptr;
     if (want_dres) {
         dres = at::empty_like(x);
         drp = dres.data_ptr();
     }
     launch_bn_bwd_elemt(dz.data_ptr(), zp, x.data_ptr(), dx.data_ptr(), drp, M, (int)C, mean.data_ptr<float>(),
-                        invstd.data_ptr<float>(), gamma.data_ptr<float>(), sums.data_ptr<float>(), (float)count, cd,
-                        relu ? 1 : 0, cur_stream(x));
-    return {dx, dres};
+                        invstd.data_ptr<float>(), gamma.data_ptr<float>(), psums.data_ptr<float>(), (int)psums.size(0),
+                        sums.data_ptr<float>(), (float)count, count_ptr(count_dev), relu ? 1 : 0, cur_stream(x));
+    return {dx, dres, sums};
 }
 
 // ------------------------------------------------------------------------------------ pools
@@ -456,26 +494,35 @@ int dtype_code(at::ScalarType st) {
     return st == at::kFloat ? kF32 : kBF16;
 }
 
-// dsts[i] <- srcs[i] * scale; every pair dense with identical strides
+// dsts[i] <- srcs[i] * scale; every pair dense with identical strides.  Pointer table in kernel args.
 void multi_flatten(std::vector<Tensor> srcs, std::vector<Tensor> dsts, double scale) {
     TORCH_CHECK(srcs.size() == dsts.size(), "multi_flatten: list size mismatch");
     if (srcs.empty()) return;
     const auto sst = srcs[0].scalar_type(), dst_t = dsts[0].scalar_type();
-    std::vector<std::vector<const Tensor*>> cols(2);
-    std::vector<int64_t> numels;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(srcs[0].device());
+    hipStream_t stream = cur_stream(srcs[0]);
+    FlatArgs a;
+    a.n = 0;
+    a.chunk_start[0] = 0;
+    auto flush = [&]() {
+        if (a.n > 0) launch_flatten_args(a, (float)scale, dtype_code(sst), dtype_code(dst_t), stream);
+        a.n = 0;
+        a.chunk_start[0] = 0;
+    };
     for (size_t i = 0; i < srcs.size(); ++i) {
         check_mt(srcs[i], sst, "src");
         check_mt(dsts[i], dst_t, "dst");
         TORCH_CHECK(srcs[i].numel() == dsts[i].numel() && srcs[i].strides() == dsts[i].strides(),
                     "multi_flatten: src/dst must have the same dense layout");
-        cols[0].push_back(&srcs[i]);
-        cols[1].push_back(&dsts[i]);
-        numels.push_back(srcs[i].numel());
+        TORCH_CHECK(srcs[i].numel() < (1L << 31), "multi_flatten: tensor too large");
+        if (srcs[i].numel() == 0) continue;
+        a.src[a.n] = srcs[i].data_ptr();
+        a.dst[a.n] = dsts[i].data_ptr();
+        a.numel[a.n] = (int)srcs[i].numel();
+        a.chunk_start[a.n + 1] = a.chunk_start[a.n] + (int)((srcs[i].numel() + kMTChunk - 1) / kMTChunk);
+        if (++a.n == kFlatMax) flush();
     }
-    c10::hip::HIPGuardMasqueradingAsCUDA guard(srcs[0].device());
-    const Table& t = get_table(cols, numels, srcs[0].device());
-    launch_multi_flatten(t.dev.data_ptr<int64_t>(), t.ntensors, t.nchunks, (float)scale, dtype_code(sst),
-                         dtype_code(dst_t), cur_stream(srcs[0]));
+    flush();
 }
 
 void fill_cols(const std::vector<Tensor>& ps, const std::vector<Tensor>& gs, const std::vector<Tensor>* ms,
@@ -554,6 +601,7 @@ void bind_ops(pybind11::module& m) {
     m.def("transpose_weight", &transpose_weight);
     m.def("bn_stats", &bn_stats);
     m.def("bn_finalize", &bn_finalize);
+    m.def("bn_sum_partials", &bn_sum_partials);
     m.def("bn_apply_act", &bn_apply_act);
     m.def("bn_bwd_reduce", &bn_bwd_reduce);
     m.def("bn_bwd_elemt", &bn_bwd_elemt);

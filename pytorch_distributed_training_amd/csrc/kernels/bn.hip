@@ -90,24 +90,55 @@ __global__ __launch_bounds__(kThreads) void k_bn_stats(const bf16* __restrict__ 
     block_reduce_store(m, C, s, q, slab);
 }
 
-__global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restrict__ stats, int C, float count,
-                                                          const float* __restrict__ count_dev, float eps,
+// stats: partial rows [nparts][2][C] (conv epilogue / stats kernel).  256 threads = 8 row lanes x 32
+// channels: the partial rows are summed here (fixed order -> deterministic), so no separate
+// reduction launch sits between the conv and the normalisation.  Thread 0 also bumps
+// num_batches_tracked: one launch does everything the reference needs 3 kernels + a host add for.
+__global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restrict__ stats, int nparts, int C,
+                                                          float count, const float* __restrict__ count_dev, float eps,
                                                           float momentum, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float* __restrict__ mean,
-                                                          float* __restrict__ invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float n = count_dev ? count_dev[0] : count;
-    const float mu = stats[c] / n;
-    float var = stats[C + c] / n - mu * mu;
-    var = var > 0.f ? var : 0.f;
-    mean[c] = mu;
-    invstd[c] = rsqrtf(var + eps);
-    if (running_mean) {
-        const float unbiased = var * (n / fmaxf(n - 1.f, 1.f));
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+                                                          float* __restrict__ running_var,
+                                                          long* __restrict__ num_batches_tracked,
+                                                          float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* __restrict__ sums_out) {
+    __shared__ float red[8][32][2];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        for (int p = rl; p < nparts; p += 8) {
+            s += stats[(long)p * 2 * C + c];
+            q += stats[(long)p * 2 * C + C + c];
+        }
     }
+    red[rl][cl][0] = s;
+    red[rl][cl][1] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) {
+            s += red[r][cl][0];
+            q += red[r][cl][1];
+        }
+        if (sums_out) {
+            sums_out[c] = s;
+            sums_out[C + c] = q;
+        }
+        if (mean) {
+            const float n = count_dev ? count_dev[0] : count;
+            const float mu = s / n;
+            float var = q / n - mu * mu;
+            var = var > 0.f ? var : 0.f;
+            mean[c] = mu;
+            invstd[c] = rsqrtf(var + eps);
+            if (running_mean) {
+                const float unbiased = var * (n / fmaxf(n - 1.f, 1.f));
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            }
+        }
+    }
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
 }
 
 template <bool RELU, bool RES>
@@ -190,7 +221,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ sums, float count,
+                                                           const float* __restrict__ psums, int nps,
+                                                           float* __restrict__ sums_out, float count,
                                                            const float* __restrict__ count_dev) {
     const Map m = make_map(C);
     long r0, r1;
@@ -198,12 +230,28 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
     const float invn = 1.f / (count_dev ? count_dev[0] : count);
     float k1[8], k2[8], k3[8];
     {
-        float mu[8], is[8], ga[8], sa[8], sb[8];
+        float mu[8], is[8], ga[8], sa[8] = {0}, sb[8] = {0};
         ld8f(mean + m.cg * 8, mu);
         ld8f(invstd + m.cg * 8, is);
         ld8f(gamma + m.cg * 8, ga);
-        ld8f(sums + m.cg * 8, sa);
-        ld8f(sums + C + m.cg * 8, sb);
+        // second reduction level fused here: psums is [nps <= 32][2][C] (fixed order -> deterministic)
+        for (int p = 0; p < nps; ++p) {
+            float ta[8], tb[8];
+            ld8f(psums + (long)p * 2 * C + m.cg * 8, ta);
+            ld8f(psums + (long)p * 2 * C + C + m.cg * 8, tb);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sa[k] += ta[k];
+                sb[k] += tb[k];
+            }
+        }
+        if (sums_out != nullptr && blockIdx.x == 0 && m.rl == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sums_out[m.cg * 8 + k] = sa[k];
+                sums_out[C + m.cg * 8 + k] = sb[k];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float g_is = ga[k] * is[k];
@@ -236,7 +284,7 @@ int grid_for(long M, int C) {
     const int R = kThreads / (C >> 3);
     long parts = (M + (long)R * 16 - 1) / ((long)R * 16);
     if (parts < 1) parts = 1;
-    if (parts > 1024) parts = 1024;
+    if (parts > 512) parts = 512;
     return (int)parts;
 }
 
@@ -249,10 +297,11 @@ void launch_bn_stats(const void* x, long M, int C, float* slab, int parts, hipSt
     hipLaunchKernelGGL(k_bn_stats, dim3(parts), dim3(kThreads), lds, s, (const bf16*)x, M, C, slab);
 }
 
-void launch_bn_finalize(const float* stats, int C, float count, const float* count_dev, float eps, float momentum,
-                        float* running_mean, float* running_var, float* mean, float* invstd, hipStream_t s) {
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, s, stats, C, count,
-                       count_dev, eps, momentum, running_mean, running_var, mean, invstd);
+void launch_bn_finalize(const float* stats, int nparts, int C, float count, const float* count_dev, float eps,
+                        float momentum, float* running_mean, float* running_var, long* num_batches_tracked,
+                        float* mean, float* invstd, float* sums_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(kThreads), 0, s, stats, nparts, C, count, count_dev,
+                       eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd, sums_out);
 }
 
 void launch_bn_apply(const void* x, const void* residual, void* z, long M, int C, const float* mean,
@@ -284,8 +333,8 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, 
 }
 
 void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx, void* dres, long M, int C,
-                         const float* mean, const float* invstd, const float* gamma, const float* sums,
-                         float count, const float* count_dev, int relu, hipStream_t s) {
+                         const float* mean, const float* invstd, const float* gamma, const float* psums, int nps,
+                         float* sums_out, float count, const float* count_dev, int relu, hipStream_t s) {
     const int R = kThreads / (C >> 3);
     long blocks = (M + (long)R * 8 - 1) / ((long)R * 8);
     if (blocks > 2048) blocks = 2048;
@@ -293,7 +342,8 @@ void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx,
     dim3 grid((int)blocks), block(kThreads);
 #define PDT_ELEMT(RELU, DRES)                                                                                  \
     hipLaunchKernelGGL((k_bn_bwd_elemt<RELU, DRES>), grid, block, 0, s, (const bf16*)dz, (const bf16*)z,       \
-                       (const bf16*)x, (bf16*)dx, (bf16*)dres, M, C, mean, invstd, gamma, sums, count, count_dev)
+                       (const bf16*)x, (bf16*)dx, (bf16*)dres, M, C, mean, invstd, gamma, psums, nps, sums_out, count,   \
+                       count_dev)
     if (relu && dres) PDT_ELEMT(true, true);
     else if (relu) PDT_ELEMT(true, false);
     else if (dres) PDT_ELEMT(false, true);

@@ -90,6 +90,34 @@ __global__ __launch_bounds__(256) void k_multi_flatten(const int64_t* __restrict
     }
 }
 
+// Same copy, but the pointer table travels in the kernel arguments (<= kFlatMax tensors per launch):
+// gradient tensors are re-allocated every step, so a cached device table would miss each time and
+// cost a synchronous H2D copy on the autograd thread.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void k_flatten_args(const FlatArgs a, float scale) {
+    // binary search: largest t with chunk_start[t] <= blockIdx.x
+    int lo = 0, hi = a.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.chunk_start[mid] <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const S* src = reinterpret_cast<const S*>(a.src[lo]);
+    D* dst = reinterpret_cast<D*>(a.dst[lo]);
+    const long n = a.numel[lo];
+    const long base = (long)((int)blockIdx.x - a.chunk_start[lo]) * kMTChunk;
+#pragma unroll
+    for (int it = 0; it < kMTChunk / (256 * 4); ++it) {
+        const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+        if (i >= n) break;
+        float v[4];
+        load4<S>(src, i, n, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= scale;
+        store4(dst, i, n, v);
+    }
+}
+
 // row: p0 = param (f32), p1 = grad, p2 = exp_avg, p3 = exp_avg_sq, p4 = bf16 copy or 0
 template <typename G>
 __global__ __launch_bounds__(256) void k_multi_adam(const int64_t* __restrict__ table, int ntensors, float lr,
@@ -261,6 +289,20 @@ void launch_multi_flatten(const int64_t* table, int ntensors, int nchunks, float
         hipLaunchKernelGGL((k_multi_flatten<bf16, bf16>), grid, block, 0, s, table, ntensors, scale);
 }
 
+void launch_flatten_args(const FlatArgs& a, float scale, int src_dtype, int dst_dtype, hipStream_t s) {
+    const int nchunks = a.chunk_start[a.n];
+    if (a.n <= 0 || nchunks <= 0) return;
+    dim3 grid(nchunks), block(256);
+    if (src_dtype == kF32 && dst_dtype == kF32)
+        hipLaunchKernelGGL((k_flatten_args<float, float>), grid, block, 0, s, a, scale);
+    else if (src_dtype == kF32 && dst_dtype == kBF16)
+        hipLaunchKernelGGL((k_flatten_args<float, bf16>), grid, block, 0, s, a, scale);
+    else if (src_dtype == kBF16 && dst_dtype == kF32)
+        hipLaunchKernelGGL((k_flatten_args<bf16, float>), grid, block, 0, s, a, scale);
+    else
+        hipLaunchKernelGGL((k_flatten_args<bf16, bf16>), grid, block, 0, s, a, scale);
+}
+
 void launch_multi_adam(const int64_t* table, int ntensors, int nchunks, float lr, float beta1, float beta2,
                        float eps, float weight_decay, float bias_corr1, float bias_corr2_sqrt, int adamw,
                        float grad_scale, int grad_dtype, hipStream_t s) {
@@ -318,6 +360,14 @@ void launch_reduce_slab(const float* slab, int nparts, long stride, int n, float
     } else {
         hipLaunchKernelGGL(k_reduce_slab, dim3(colblocks, 1), dim3(256), 0, s, slab, nparts, stride, n, nparts, out);
     }
+}
+
+int launch_reduce_rows_l1(const float* slab, int nparts, long stride, int n, float* out, hipStream_t s) {
+    const int colblocks = (n + 255) / 256;
+    const int ppc = (nparts + kReduceChunks - 1) / kReduceChunks;
+    const int chunks = (nparts + ppc - 1) / ppc;
+    hipLaunchKernelGGL(k_reduce_slab, dim3(colblocks, chunks), dim3(256), 0, s, slab, nparts, stride, n, ppc, out);
+    return chunks;
 }
 
 }  // namespace pdt

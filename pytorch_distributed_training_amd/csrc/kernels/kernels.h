@@ -14,6 +14,16 @@ constexpr int kMTChunk = 4096;
 constexpr int kMTCols = 8;
 void launch_multi_flatten(const int64_t* table, int ntensors, int nchunks, float scale, int src_dtype,
                           int dst_dtype, hipStream_t s);
+// bucket flatten with the table in the kernel arguments (no device table, no H2D)
+constexpr int kFlatMax = 64;
+struct FlatArgs {
+    const void* src[kFlatMax];
+    void* dst[kFlatMax];
+    int numel[kFlatMax];
+    int chunk_start[kFlatMax + 1];  // prefix sums of 4096-element chunks; chunk_start[n] = total
+    int n;
+};
+void launch_flatten_args(const FlatArgs& a, float scale, int src_dtype, int dst_dtype, hipStream_t s);
 void launch_multi_adam(const int64_t* table, int ntensors, int nchunks, float lr, float beta1, float beta2,
                        float eps, float weight_decay, float bias_corr1, float bias_corr2_sqrt, int adamw,
                        float grad_scale, int grad_dtype, hipStream_t s);
@@ -31,6 +41,8 @@ void launch_transpose_ntc(const void* w, void* wt, int N, int T, int C, hipStrea
 // workspace, required when nparts > 64 (two-level reduction).
 constexpr int kReduceChunks = 32;
 void launch_reduce_slab(const float* slab, int nparts, long stride, int n, float* out, float* tmp, hipStream_t s);
+// first level only: out[kReduceChunks][n] gets <= kReduceChunks partial rows; returns the row count
+int launch_reduce_rows_l1(const float* slab, int nparts, long stride, int n, float* out, hipStream_t s);
 
 // ---- softmax cross-entropy (mean), fwd + bwd in one pass -------------------------------------
 void launch_softmax_ce(const void* logits, int dtype, const int64_t* labels, int B, int N, float* row_loss,
@@ -39,18 +51,20 @@ void launch_softmax_ce(const void* logits, int dtype, const int64_t* labels, int
 // ---- batch norm (NHWC bf16, per-channel vectors fp32) ----------------------------------------
 int bn_parts(long M, int C);  // number of partial rows the stats / bwd-reduce kernels write
 void launch_bn_stats(const void* x, long M, int C, float* slab /*[parts][2][C]*/, int parts, hipStream_t s);
-// stats[2][C] + count (device scalar if count_dev != nullptr) -> mean, invstd; optional running update
-void launch_bn_finalize(const float* stats, int C, float count, const float* count_dev, float eps,
-                        float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
-                        hipStream_t s);
+// stats: partial rows [nparts][2][C] (nparts <= 512).  Sums them, writes mean / invstd, updates the
+// running stats and num_batches_tracked (each optional) and optionally the reduced sums [2][C].
+void launch_bn_finalize(const float* stats, int nparts, int C, float count, const float* count_dev, float eps,
+                        float momentum, float* running_mean, float* running_var, long* num_batches_tracked,
+                        float* mean, float* invstd, float* sums_out, hipStream_t s);
 void launch_bn_apply(const void* x, const void* residual, void* z, long M, int C, const float* mean,
                      const float* invstd, const float* gamma, const float* beta, int relu, hipStream_t s);
 void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, int C, const float* mean,
                           const float* invstd, int relu, float* slab /*[parts][2][C]*/, int parts,
                           hipStream_t s);
 void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx, void* dres, long M, int C,
-                         const float* mean, const float* invstd, const float* gamma, const float* sums,
-                         float count, const float* count_dev, int relu, hipStream_t s);
+                         const float* mean, const float* invstd, const float* gamma, const float* psums /*[nps][2][C]*/,
+                         int nps, float* sums_out /*[2][C] or null*/, float count, const float* count_dev, int relu,
+                         hipStream_t s);
 
 // ---- pools (NHWC bf16) -----------------------------------------------------------------------
 void launch_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int B, int H, int W, int C, int Ho, int Wo,

@@ -55,6 +55,7 @@ class _Conv2dFn(torch.autograd.Function):
                 _note_fallback("conv2d", why)
                 be = reference
         y, stats = be.conv2d_fwd(x, wk, stride, padding, want_stats)
+        ctx.set_materialize_grads(False)  # no zero-filled gradient for the (non-differentiable) stats output
         ctx.save_for_backward(x, wk)
         ctx.cfg = (be, stride, padding, tuple(w.shape), w.dtype)
         if stats is not None:
@@ -65,6 +66,8 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy, _dstats):
         x, wk = ctx.saved_tensors
         be, stride, padding, w_shape, w_dtype = ctx.cfg
+        if dy is None:
+            return None, None, None, None, None, None
         dy = _cl(dy)
         dx = dw = None
         if ctx.needs_input_grad[0]:
@@ -78,7 +81,7 @@ class _Conv2dFn(torch.autograd.Function):
 
 def conv2d(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = False):
     """Bias-free square-stride conv.  Returns ``(y, stats)`` where ``stats`` is the
-    fp32 ``[2, Cout]`` per-channel ``[sum, sum_sq]`` of ``y`` (or ``None``)."""
+    fp32 partial rows ``[P, 2, Cout]`` of the per-channel ``[sum, sum_sq]`` of ``y`` (or ``None``)."""
     w_lp = getattr(weight, "_lp", None)
     if w_lp is not None and w_lp.dtype != x.dtype:
         w_lp = None
@@ -127,21 +130,20 @@ class _BNActFn(torch.autograd.Function):
                 stats = be.bn_stats(x)
             if world > 1:
                 # [sum(C), sum_sq(C), count]: one all-reduce, counts may differ per rank
-                packed = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)
-                packed[: 2 * c].copy_(stats.reshape(-1))
-                packed[2 * c] = count
+                packed = torch.empty(2 * c + 4, dtype=torch.float32, device=x.device)
+                packed[: 2 * c].copy_(be.bn_sum_partials(stats).reshape(-1))
+                packed[2 * c:] = count
                 tdist.all_reduce(packed, group=cfg.group)
-                stats = packed[: 2 * c].view(2, c)
-                count_t = packed[2 * c:]
+                stats = packed[: 2 * c].view(1, 2, c)
+                count_t = packed[2 * c: 2 * c + 1]
             cnt = count_t if count_t is not None else count
             mom = 0.0
             if cfg.running_mean is not None:
-                if cfg.num_batches_tracked is not None:
-                    cfg.num_batches_tracked.add_(1)
                 mom = cfg.momentum
-                if mom is None:  # cumulative moving average
-                    mom = 1.0 / float(cfg.num_batches_tracked.item())
-            mean, invstd = be.bn_finalize(stats.float(), cnt, cfg.eps, cfg.running_mean, cfg.running_var, mom)
+                if mom is None:  # cumulative moving average (host sync, like the stock module)
+                    mom = 1.0 / (float(cfg.num_batches_tracked.item()) + 1.0)
+            mean, invstd = be.bn_finalize(stats, cnt, cfg.eps, cfg.running_mean, cfg.running_var, mom,
+                                          cfg.num_batches_tracked if cfg.running_mean is not None else None)
         else:
             mean = cfg.running_mean.float()
             invstd = torch.rsqrt(cfg.running_var.float() + cfg.eps)
@@ -158,22 +160,23 @@ class _BNActFn(torch.autograd.Function):
         x, z, mean, invstd, g32, count_t = ctx.saved_tensors
         be, cfg, relu, world, count, has_res, gdt, bdt = ctx.cfg
         dz = _cl(dz)
-        sums = be.bn_bwd_reduce(dz, z, x, mean, invstd, relu)  # local [2, C]
+        psums = be.bn_bwd_reduce(dz, z, x, mean, invstd, relu)  # local partial rows [P, 2, C]
+        want_dres = has_res and ctx.needs_input_grad[3]
+        if cfg.training and world > 1:
+            # the affine grads stay local (DDP averages them); the sums that feed grad_input are global
+            sums = be.bn_sum_partials(psums)
+            gsums = sums.clone()
+            tdist.all_reduce(gsums, group=cfg.group)
+            dx, dres, _ = be.bn_bwd_elemt(dz, z, x, mean, invstd, g32, gsums.view(1, 2, -1), count_t, relu, want_dres)
+        elif cfg.training:
+            dx, dres, sums = be.bn_bwd_elemt(dz, z, x, mean, invstd, g32, psums, count, relu, want_dres)
+        else:
+            # eval-mode BN: statistics are constants, no reduction terms in grad_input
+            sums = be.bn_sum_partials(psums)
+            dx, dres, _ = be.bn_bwd_elemt(dz, z, x, mean, invstd, g32, torch.zeros_like(sums).view(1, 2, -1), 1.0,
+                                          relu, want_dres)
         dgamma = sums[1].to(gdt) if (gdt is not None and ctx.needs_input_grad[1]) else None
         dbeta = sums[0].to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
-        if cfg.training:
-            gsums, cnt = sums, count
-            if world > 1:
-                # the affine grads above stay local (DDP averages them); the sums that
-                # feed grad_input must be global
-                gsums = sums.clone()
-                tdist.all_reduce(gsums, group=cfg.group)
-                cnt = count_t
-        else:
-            # eval-mode BN: statistics are constants, no reduction terms
-            gsums, cnt = torch.zeros_like(sums), 1.0
-        dx, dres = be.bn_bwd_elemt(dz, z, x, mean, invstd, g32, gsums, cnt, relu,
-                                   has_res and ctx.needs_input_grad[3])
         if not ctx.needs_input_grad[0]:
             dx = None
         return dx, dgamma, dbeta, dres, None, None, None

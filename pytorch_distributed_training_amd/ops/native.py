@@ -78,10 +78,18 @@ def _count_args(count):
     return float(count), None
 
 
-def bn_finalize(stats, count, eps: float, running_mean=None, running_var=None, momentum: float = 0.0):
-    """mean / invstd (+ the in-place running-stat update) in ONE tiny launch, no host sync."""
+def bn_sum_partials(stats):
+    return _C.bn_sum_partials(stats.contiguous()) if stats.dim() == 3 else stats
+
+
+def bn_finalize(stats, count, eps: float, running_mean=None, running_var=None, momentum: float = 0.0,
+                num_batches_tracked=None):
+    """Partial rows [P,2,C] -> mean / invstd, + in-place running stats and num_batches_tracked:
+    ONE tiny launch, no host sync."""
     c, cd = _count_args(count)
-    return _C.bn_finalize(stats.contiguous(), c, cd, eps, momentum, running_mean, running_var)
+    if stats.dim() == 2:
+        stats = stats[None]
+    return _C.bn_finalize(stats.contiguous(), c, cd, eps, momentum, running_mean, running_var, num_batches_tracked)
 
 
 def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False):
@@ -92,11 +100,13 @@ def bn_bwd_reduce(dz, z, x, mean, invstd, relu: bool):
     return _C.bn_bwd_reduce(dz, z if relu else None, x, mean, invstd, relu)
 
 
-def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sums, count, relu: bool, want_dres: bool):
+def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, psums, count, relu: bool, want_dres: bool):
     c, cd = _count_args(count)
-    dx, dres = _C.bn_bwd_elemt(dz, z if relu else None, x, mean, invstd, gamma.contiguous(),
-                               sums.contiguous().view(-1), c, cd, relu, want_dres)
-    return dx, (dres if want_dres else None)
+    if psums.dim() == 2:
+        psums = psums[None]
+    dx, dres, sums = _C.bn_bwd_elemt(dz, z if relu else None, x, mean, invstd, gamma.contiguous(),
+                                     psums.contiguous(), c, cd, relu, want_dres)
+    return dx, (dres if want_dres else None), sums
 
 
 # -------------------------------------------------------------------- pools

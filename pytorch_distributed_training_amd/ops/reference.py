@@ -18,7 +18,7 @@ def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False):
     y = F.conv2d(x, w.to(x.dtype), None, stride, padding)
     if want_stats:
         yf = y.float()
-        stats = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))], 0)  # [2, C]
+        stats = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))], 0)[None]  # partial rows [1, 2, C]
         return y, stats
     return y, None
 
@@ -38,14 +38,25 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, padding: int):
 
 # ------------------------------------------------------------ batchnorm ----
 def bn_stats(x):
-    """Per-channel ``[sum, sum_sq]`` in fp32, shape ``[2, C]``."""
+    """Per-channel ``[sum, sum_sq]`` in fp32 as partial rows ``[P, 2, C]`` (the oracle has P = 1;
+    the HIP kernels emit one row per block / conv tile and the consumer sums them)."""
     xf = x.float()
-    return torch.stack([xf.sum((0, 2, 3)), (xf * xf).sum((0, 2, 3))], 0)
+    return torch.stack([xf.sum((0, 2, 3)), (xf * xf).sum((0, 2, 3))], 0)[None]
 
 
-def bn_finalize(stats, count, eps: float, running_mean=None, running_var=None, momentum: float = 0.0):
-    """``[2,C]`` sums + element count (float or 1-element tensor) -> (mean, invstd) with the
-    biased variance; updates the running stats in place (unbiased variance, torch semantics)."""
+def bn_sum_partials(stats):
+    """``[P, 2, C] -> [2, C]``"""
+    return stats.sum(0) if stats.dim() == 3 else stats
+
+
+def bn_finalize(stats, count, eps: float, running_mean=None, running_var=None, momentum: float = 0.0,
+                num_batches_tracked=None):
+    """partial sums ``[P,2,C]`` + element count (float or 1-element tensor) -> (mean, invstd) with the
+    biased variance; updates the running stats (unbiased variance, torch semantics) and
+    ``num_batches_tracked`` in place."""
+    stats = bn_sum_partials(stats)
+    if num_batches_tracked is not None:
+        num_batches_tracked.add_(1)
     if torch.is_tensor(count):
         count = count.reshape(()).to(stats.dtype)
     mean = stats[0] / count
@@ -72,17 +83,19 @@ def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False
 
 
 def bn_bwd_reduce(dz, z, x, mean, invstd, relu: bool):
-    """-> ``[2, C]``: ``sum(dzm)``, ``sum(dzm * xhat)`` with ``dzm = dz * (z > 0)``."""
+    """-> partial rows ``[P, 2, C]`` of ``sum(dzm)``, ``sum(dzm * xhat)`` with ``dzm = dz * (z > 0)``."""
     g = dz.float()
     if relu:
         g = g * (z > 0)
     xhat = (x.float() - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
-    return torch.stack([g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))], 0)
+    return torch.stack([g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))], 0)[None]
 
 
-def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sums, count, relu: bool, want_dres: bool):
-    """-> ``(dx, dres)``; ``sums`` are the (globally reduced) outputs of
-    ``bn_bwd_reduce`` and ``count`` the global element count per channel."""
+def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, psums, count, relu: bool, want_dres: bool):
+    """-> ``(dx, dres, sums)``; ``psums`` are partial rows ``[P,2,C]`` of ``bn_bwd_reduce`` (or the
+    globally reduced sums as ``[1,2,C]``), ``count`` the global element count per channel and
+    ``sums`` the summed ``[2,C]``."""
+    sums = bn_sum_partials(psums)
     if torch.is_tensor(count):
         count = count.reshape(())
     g = dz.float()
@@ -92,7 +105,7 @@ def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sums, count, relu: bool, want_dr
     xhat = (x.float() - v(mean)) * v(invstd)
     dx = v(gamma * invstd) * (g - v(sums[0] / count) - xhat * v(sums[1] / count))
     dres = g.to(dz.dtype) if want_dres else None
-    return dx.to(x.dtype), dres
+    return dx.to(x.dtype), dres, sums
 
 
 # ---------------------------------------------------------------- pools ----

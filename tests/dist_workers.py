@@ -1,0 +1,194 @@
+"""Worker bodies for the multi-process CPU/gloo tests (spawned by tests/test_ddp_gloo.py)."""
+import os
+import sys
+import traceback
+
+import torch
+import torch.distributed as tdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _init(rank, world, port):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    from pytorch_distributed_training_amd import dist as pdist
+
+    torch.set_num_threads(1)
+    return pdist.init_process_group(backend="gloo", local_rank=rank)
+
+
+def run(fn_name, rank, world, port, out_dir, kwargs):
+    try:
+        _init(rank, world, port)
+        result = globals()[fn_name](rank, world, **kwargs)
+        torch.save(result, os.path.join(out_dir, f"result_{rank}.pt"))
+        tdist.barrier()
+        tdist.destroy_process_group()
+    except Exception:
+        traceback.print_exc()
+        with open(os.path.join(out_dir, f"error_{rank}.txt"), "w") as f:
+            f.write(traceback.format_exc())
+        os._exit(1)
+
+
+def _toy(seed=0, bn=True):
+    import torch.nn as tnn
+
+    from pytorch_distributed_training_amd import nn as pnn
+
+    torch.manual_seed(seed)
+
+    class Net(tnn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = pnn.Conv2d(3, 8, 3, 1, 1, bias=False)
+            self.bn1 = pnn.BatchNorm2d(8) if bn else tnn.Identity()
+            self.conv2 = pnn.Conv2d(8, 8, 3, 2, 1, bias=False)
+            self.bn2 = pnn.BatchNorm2d(8) if bn else tnn.Identity()
+            self.fc = pnn.Linear(8, 5)
+
+        def forward(self, x):
+            if bn:
+                x = self.bn1(self.conv1(x), relu=True)
+                x = self.bn2(self.conv2(x), relu=True)
+            else:
+                x = torch.relu(self.conv2(torch.relu(self.conv1(x))))
+            return self.fc(x.mean((2, 3)))
+
+    return Net()
+
+
+def _data(n=8, seed=123):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, 3, 8, 8, generator=g), torch.randint(0, 5, (n,), generator=g)
+
+
+def ddp_grads(rank, world, reducer="py", sync_bn=True, bucket_cap_mb=None, steps=1, no_sync_first=False):
+    """Gradients of DDP(+SyncBN) over a sharded batch == gradients of one process over the full batch."""
+    from pytorch_distributed_training_amd import nn as pnn
+    from pytorch_distributed_training_amd.parallel import DistributedDataParallel
+
+    net = _toy(seed=rank)  # different init per rank: the ctor broadcast must fix that
+    if sync_bn:
+        net = pnn.convert_sync_batchnorm(net)
+    ddp = DistributedDataParallel(net, reducer=reducer, bucket_cap_mb=bucket_cap_mb, first_bucket_mb=bucket_cap_mb)
+    x, y = _data()
+    per = x.shape[0] // world
+    xs, ys = x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
+    crit = pnn.CrossEntropyLoss()
+    out = {}
+    for s in range(steps):
+        for p in ddp.parameters():
+            p.grad = None
+        if no_sync_first and s == 0:
+            with ddp.no_sync():
+                crit(ddp(xs), ys).backward()
+            out["local_only"] = [p.grad.clone() for p in ddp.parameters()]
+            continue
+        loss = crit(ddp(xs), ys)
+        loss.backward()
+    out.update({
+        "grads": {n: p.grad.detach().clone() for n, p in ddp.module.named_parameters()},
+        "params": {n: p.detach().clone() for n, p in ddp.module.named_parameters()},
+        "buffers": {n: b.detach().clone() for n, b in ddp.module.named_buffers()},
+        "loss": float(loss.detach()),
+        "buckets": [list(b.param_indices) for b in ddp.reducer.bucket_specs()],
+        "rebuilt": bool(ddp.reducer.rebuilt),
+        "kind": ddp.reducer_kind,
+        "grad_is_view": all(p.grad.untyped_storage().data_ptr() in
+                            {t.untyped_storage().data_ptr() for t in _bucket_tensors(ddp)} for p in ddp.parameters()),
+    })
+    return out
+
+
+def _bucket_tensors(ddp):
+    r = ddp.reducer
+    return r.bucket_tensors() if hasattr(r, "bucket_tensors") else [b.flat for b in r.buckets]
+
+
+def train_equivalence(rank, world, reducer="native", optimizer="sgd", steps=4):
+    """A few optimizer steps with DDP == the same steps in one process on the full batch."""
+    from pytorch_distributed_training_amd import nn as pnn
+    from pytorch_distributed_training_amd.optim import build_optimizer
+    from pytorch_distributed_training_amd.parallel import DistributedDataParallel
+
+    net = _toy(seed=7)
+    opt = build_optimizer(optimizer, net.parameters(), lr=0.05)  # before conversion / wrapping (main.py:80-83)
+    net = pnn.convert_sync_batchnorm(net)
+    ddp = DistributedDataParallel(net, reducer=reducer, bucket_cap_mb=0.0005)
+    crit = pnn.CrossEntropyLoss()
+    losses = []
+    for s in range(steps):
+        x, y = _data(seed=100 + s)
+        per = x.shape[0] // world
+        out = ddp(x[rank * per:(rank + 1) * per])
+        loss = crit(out, y[rank * per:(rank + 1) * per])
+        opt.zero_grad()  # after forward, like the reference
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    ddp.assert_replicas_equal()
+    return {"params": {n: p.detach().clone() for n, p in ddp.module.named_parameters()}, "losses": losses,
+            "buffers": {n: b.detach().clone() for n, b in ddp.module.named_buffers()}}
+
+
+def reduce_loss_semantics(rank, world):
+    from pytorch_distributed_training_amd import dist as pdist
+
+    t = torch.tensor(float(rank + 1))
+    pdist.reduce_loss(t, rank, world)
+    return float(t)
+
+
+def buffer_broadcast(rank, world):
+    """Plain (non-sync) BN: per-forward buffer broadcast keeps rank 0's running stats everywhere."""
+    from pytorch_distributed_training_amd.parallel import DistributedDataParallel
+
+    net = _toy(seed=3)
+    ddp = DistributedDataParallel(net, reducer="py")
+    assert ddp.broadcast_buffers
+    x, _ = _data(seed=rank)  # different data per rank -> different local running stats
+    ddp(x)
+    ddp(x)  # second forward starts with the broadcast of rank 0's buffers
+    return {"bn1.running_mean_before_bcast": None,
+            "buffers": {n: b.detach().clone() for n, b in ddp.module.named_buffers()}}
+
+
+def checkpoint_roundtrip(rank, world, path=None):
+    from pytorch_distributed_training_amd import nn as pnn
+    from pytorch_distributed_training_amd.optim import Adam
+    from pytorch_distributed_training_amd.parallel import DistributedDataParallel
+    from pytorch_distributed_training_amd.utils import checkpoint as ckpt
+
+    net = _toy(seed=11)
+    opt = Adam(net.parameters(), lr=1e-2)
+    ddp = DistributedDataParallel(pnn.convert_sync_batchnorm(net), reducer="native")
+    crit = pnn.CrossEntropyLoss()
+    x, y = _data()
+    per = x.shape[0] // world
+    xs, ys = x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
+
+    def step():
+        loss = crit(ddp(xs), ys)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    step(); step()
+    wrote = ckpt.save_checkpoint(path, ddp, opt, epoch=1, global_step=2)
+    tdist.barrier()
+    expect = [step(), step()]
+    after = {n: p.detach().clone() for n, p in ddp.module.named_parameters()}
+    # fresh replica, resume, replay
+    net2 = _toy(seed=99)
+    opt2 = Adam(net2.parameters(), lr=1e-2)
+    meta = ckpt.load_checkpoint(path, net2, opt2)
+    ddp2 = DistributedDataParallel(pnn.convert_sync_batchnorm(net2), reducer="native")
+    ddp, opt = ddp2, opt2
+    got = [step(), step()]
+    same = all(torch.allclose(p, after[n], atol=1e-6) for n, p in ddp2.module.named_parameters())
+    return {"wrote": wrote, "meta": meta, "expect": expect, "got": got, "same": same}
