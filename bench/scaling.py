@@ -1,0 +1,106 @@
+"""Scaling benchmark: ResNet-50 bf16 DDP images/sec at 1/2/4/8 MI355X.
+
+    python bench/scaling.py --gpus 1 2 4 8 --steps 30 --warmup 10      # on a real multi-GPU node
+    python bench/scaling.py --model-from gpurun_out/bench_native_b256.log  # modelled curve from a 1-GPU run
+
+Measured mode launches ``bench.py`` through OUR launcher (one process per GPU, RCCL over xGMI) for
+each N and reports whole-job images/sec and weak-scaling efficiency ``T(N) / (N * T(1))``.
+
+Model mode (this build environment exposes one GPU per call) predicts the curve from the measured
+1-GPU step time and the xGMI cost model of SURVEY §5.8: gradient all-reduce bandwidth term with the
+per-collective latency, overlapped with backward except for the last bucket; plus the SyncBN
+latency term (2 x 53 tiny all-reduces that cannot overlap) when ``--sync_bn``.  Every modelled
+number is labelled as such.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+LINK_GBPS = 153.0          # xGMI per-link bandwidth (task brief; calibrate with a 2-GPU copy)
+COLL_LATENCY_US = 25.0     # launch + sync latency per RCCL collective (10-30 us)
+GRAD_BYTES = 25_557_032 * 4
+
+
+def run_measured(n: int, args) -> dict:
+    cmd = [sys.executable, "-m", "pytorch_distributed_training_amd.launch", f"--nproc_per_node={n}",
+           "--master_addr=127.0.0.1", f"--master_port={29600 + n}", "--use_env", os.path.join(ROOT, "bench.py"),
+           "--gpus", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch_size",
+           str(args.batch_size)] + (["--sync_bn"] if args.sync_bn else [])
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)
+    if out.returncode != 0:
+        raise RuntimeError(f"N={n} failed:\n{out.stderr[-3000:]}")
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def model_curve(step_ms_1gpu: float, batch: int, sync_bn: bool, bucket_mb: float = 16.0, algo: str = "ring"):
+    """Predicted whole-job images/sec for N in {1,2,4,8}."""
+    rows = []
+    for n in (1, 2, 4, 8):
+        if n == 1:
+            t = step_ms_1gpu
+        else:
+            if algo == "ring":      # one link per direction: 2 (N-1)/N * S over one link
+                bw_ms = 2.0 * (n - 1) / n * GRAD_BYTES / (LINK_GBPS * 1e9) * 1e3
+            else:                   # two-shot direct over the full mesh: 2 S / N per link
+                bw_ms = 2.0 * GRAD_BYTES / n / (LINK_GBPS * 1e9) * 1e3
+            n_buckets = 1 + int((GRAD_BYTES / (1 << 20) + bucket_mb - 1) // bucket_mb)
+            comm_ms = bw_ms + n_buckets * COLL_LATENCY_US * 1e-3
+            backward_ms = step_ms_1gpu * 0.6  # what the all-reduce can hide under
+            exposed = max(0.0, comm_ms - backward_ms) + bw_ms / n_buckets + COLL_LATENCY_US * 1e-3  # tail bucket
+            syncbn = 2 * 53 * COLL_LATENCY_US * 1e-3 if sync_bn else 0.0
+            t = step_ms_1gpu + exposed + syncbn
+        rows.append({"n_gpus": n, "ms_per_step": round(t, 3), "images_per_sec": round(n * batch / t * 1e3, 1),
+                     "efficiency": round(step_ms_1gpu / t, 4), "kind": "measured" if n == 1 else "modelled"})
+    return rows
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, nargs="+", default=[1, 2, 4, 8])
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch_size", type=int, default=256)
+    ap.add_argument("--sync_bn", action="store_true")
+    ap.add_argument("--model-from", dest="model_from", default=None, help="bench.py JSON line/log of a 1-GPU run")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    if a.model_from:
+        line = [l for l in open(a.model_from).read().splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        assert d["n_gpus"] == 1
+        batch = d["config"]["per_gpu_batch"]
+        result = {"source": a.model_from, "link_GBps": LINK_GBPS, "collective_latency_us": COLL_LATENCY_US,
+                  "ring": model_curve(d["ms_per_step"], batch, a.sync_bn, algo="ring"),
+                  "direct": model_curve(d["ms_per_step"], batch, a.sync_bn, algo="direct")}
+    else:
+        import torch
+
+        avail = torch.cuda.device_count()
+        rows, base = [], None
+        for n in a.gpus:
+            if n > avail:
+                print(f"skipping N={n}: only {avail} GPU(s) visible", file=sys.stderr)
+                continue
+            d = run_measured(n, a)
+            base = base or d["value"] / d["n_gpus"]
+            rows.append({"n_gpus": n, "images_per_sec": d["value"], "ms_per_step": d["ms_per_step"],
+                         "efficiency": round(d["value"] / (n * base), 4), "kind": "measured"})
+        result = {"measured": rows}
+    text = json.dumps(result, indent=2)
+    print(text)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(text + "\n")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

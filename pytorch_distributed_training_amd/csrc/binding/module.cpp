@@ -14,8 +14,10 @@ PYBIND11_MODULE(_C, m) {
     pdt::bind_ops(m);
 
     py::class_<pdt::RcclComm, std::shared_ptr<pdt::RcclComm>>(m, "RcclComm")
-        .def(py::init([](int rank, int world, py::bytes id, int device, bool high_priority) {
-                 return std::make_shared<pdt::RcclComm>(rank, world, std::string(id), device, high_priority);
+        // unique_id arrives as std::string (converted from bytes while the GIL is still held); the
+        // blocking ncclCommInitRank then runs without the GIL
+        .def(py::init([](int rank, int world, const std::string& id, int device, bool high_priority) {
+                 return std::make_shared<pdt::RcclComm>(rank, world, id, device, high_priority);
              }),
              py::arg("rank"), py::arg("world_size"), py::arg("unique_id"), py::arg("device"),
              py::arg("high_priority") = true, py::call_guard<py::gil_scoped_release>())

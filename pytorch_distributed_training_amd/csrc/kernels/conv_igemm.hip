@@ -23,25 +23,33 @@
 //    lane on full rows.
 //  * block -> tile map is XCD-aware: the 8 XCDs get contiguous tile ranges, n-tiles fastest,
 //    so blocks sharing an activation tile hit the same 4 MiB L2.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace pdt {
 namespace {
 
-constexpr int BK = 64;            // channels per K-step
-constexpr int ROWB = BK * 2;      // bytes per LDS row (128)
+// LDS rows hold BK channels (ROWB = 2*BK bytes).  A ds_read_b128 lane group covers 16 rows at one
+// chunk; rows are spread over the 256-B bank row by XOR-ing the chunk with (row / rows_per_bank_row).
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    constexpr int ROWB = BK * 2, CPR = ROWB / 16, RPB = 256 / ROWB;
+    return row * ROWB + ((chunk ^ ((row / RPB) & (CPR - 1))) << 4);
+}
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ x, const bf16* __restrict__ w,
+template <int BM, int BN, int WM, int WN, int BK, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                        bf16* __restrict__ y, const ConvGeom g,
                                                        float* __restrict__ stats_slab, int m_tiles, int n_tiles,
                                                        uint32_t x_bytes, uint32_t w_bytes) {
     static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int ROWB = BK * 2;           // bytes per LDS row
+    constexpr int CPR = ROWB / 16;         // 16-B chunks per row = threads staging one row
+    constexpr int RPP = 256 / CPR;         // rows staged per pass
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int PA = BM / RPP, PB = BN / RPP;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                  // [2][BM][128 B]
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int lrow = tid >> 3, chunk = tid & 7;
+    const int lrow = tid / CPR, chunk = tid % CPR;
 
     // XCD-aware, bijective block -> tile map (blocks b and b+8 share an XCD)
     const int total = m_tiles * n_tiles;
@@ -69,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
     int rowpix[PA], rih[PA], riw[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const long m = (long)tile_m * BM + p * 32 + lrow;
+        const long m = (long)tile_m * BM + p * RPP + lrow;
         if (m < M) {
             const int j = (int)(m % g.nOW);
             const long t1 = m / g.nOW;
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
     uint32_t wrow[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-        const int n = tile_n * BN + p * 32 + lrow;
+        const int n = tile_n * BN + p * RPP + lrow;
         wrow[p] = (n < g.N) ? (uint32_t)n * (uint32_t)g.wtaps : 0xffffffffu;
     }
 
@@ -110,10 +118,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
     auto lds_store = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < PA; ++p)
-            *reinterpret_cast<bf16x8*>(As + buf * A_BYTES + lds_off(p * 32 + lrow, chunk)) = ra[p];
+            *reinterpret_cast<bf16x8*>(As + buf * A_BYTES + lds_off<BK>(p * RPP + lrow, chunk)) = ra[p];
 #pragma unroll
         for (int p = 0; p < PB; ++p)
-            *reinterpret_cast<bf16x8*>(Bs + buf * B_BYTES + lds_off(p * 32 + lrow, chunk)) = rb[p];
+            *reinterpret_cast<bf16x8*>(Bs + buf * B_BYTES + lds_off<BK>(p * RPP + lrow, chunk)) = rb[p];
     };
 
     f32x16 acc[TM][TN];
@@ -153,10 +161,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(Ab + lds_off(arow0 + i * 32, 2 * s + khalf));
+                af[i] = *reinterpret_cast<const bf16x8*>(Ab + lds_off<BK>(arow0 + i * 32, 2 * s + khalf));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + lds_off(brow0 + j * 32, 2 * s + khalf));
+                bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + lds_off<BK>(brow0 + j * 32, 2 * s + khalf));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -222,13 +230,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
     }
 
     constexpr int CH = BN / 8;          // 16-B chunks per output row
-    constexpr int RPP = 256 / CH;       // rows per pass
+    constexpr int ORPP = 256 / CH;      // output rows per pass
     const int orow = tid / CH, och = tid % CH;
     const bool dense = (g.os == 1 && g.nOH == g.Hout && g.nOW == g.Wout);
     const int ncol = tile_n * BN + och * 8;
 #pragma unroll
-    for (int p = 0; p < BM / RPP; ++p) {
-        const int row = p * RPP + orow;
+    for (int p = 0; p < BM / ORPP; ++p) {
+        const int row = p * ORPP + orow;
         const long m = (long)tile_m * BM + row;
         if (m < M && ncol < g.N) {
             long pix;
@@ -247,24 +255,32 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK, int MINW>
 void launch_cfg(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab, hipStream_t s) {
     const long M = (long)g.B * g.nOH * g.nOW;
     const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = (g.N + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * ROWB;
+    size_t lds = (size_t)2 * (BM + BN) * BK * 2;                      // double-buffered operand tiles
+    const size_t epi = (size_t)BM * BN * 2 + (size_t)WM * BN * 2 * 4;  // staged output tile + stats scratch
+    if (lds < epi) lds = epi;
     const uint32_t xb = (uint32_t)((long)g.B * g.Hin * g.Win * g.C * 2);
     const uint32_t wb = (uint32_t)((long)g.N * g.wtaps * g.C * 2);
     static bool attr_set = false;
     if (!attr_set) {
-        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<BM, BN, WM, WN>),
+        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<BM, BN, WM, WN, BK, MINW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), dim3(m_tiles * n_tiles), dim3(256), lds, s, (const bf16*)x,
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, BK, MINW>), dim3(m_tiles * n_tiles), dim3(256), lds, s, (const bf16*)x,
                        (const bf16*)w, (bf16*)y, g, stats_slab, m_tiles, n_tiles, xb, wb);
 }
 
-inline bool use_bn128(const ConvGeom& g) { return g.N % 128 == 0; }
+int igemm_cfg_override() {
+    static int v = [] {
+        const char* e = std::getenv("PDT_IGEMM_CFG");
+        return e ? std::atoi(e) : 0;
+    }();
+    return v;
+}
 
 }  // namespace
 
@@ -276,10 +292,37 @@ int conv_igemm_m_tiles(const ConvGeom& g, int* bm_out) {
 
 void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab,
                        hipStream_t s) {
-    if (use_bn128(g))
-        launch_cfg<128, 128, 2, 2>(x, w, y, g, stats_slab, s);
-    else
-        launch_cfg<128, 64, 4, 1>(x, w, y, g, stats_slab, s);
+    const bool n128 = g.N % 128 == 0;
+    switch (igemm_cfg_override()) {  // experiment knob; 0 = tuned default.  All configs use BM = 128.
+        case 5:  // BK=64 everywhere (the round-1 baseline)
+            if (n128) launch_cfg<128, 128, 2, 2, 64, 2>(x, w, y, g, stats_slab, s);
+            else launch_cfg<128, 64, 4, 1, 64, 2>(x, w, y, g, stats_slab, s);
+            return;
+        case 1:  // BK=32, 3 waves/SIMD
+            if (n128) launch_cfg<128, 128, 2, 2, 32, 3>(x, w, y, g, stats_slab, s);
+            else launch_cfg<128, 64, 4, 1, 32, 3>(x, w, y, g, stats_slab, s);
+            return;
+        case 2:  // BK=32, 4 waves/SIMD (register-capped at 128)
+            if (n128) launch_cfg<128, 128, 2, 2, 32, 4>(x, w, y, g, stats_slab, s);
+            else launch_cfg<128, 64, 4, 1, 32, 4>(x, w, y, g, stats_slab, s);
+            return;
+        case 3:  // BK=64 but always the narrow 128x64 tile (more blocks for small-M layers)
+            launch_cfg<128, 64, 4, 1, 64, 2>(x, w, y, g, stats_slab, s);
+            return;
+        case 4:  // BK=32 narrow tile, 4 waves/SIMD
+            launch_cfg<128, 64, 4, 1, 32, 4>(x, w, y, g, stats_slab, s);
+            return;
+        default:
+            // measured on MI355X (profiles/r1_igemm_cfg_sweep.md): short-K pointwise GEMMs are HBM/latency
+            // bound and want occupancy (BK=32, 4 blocks/CU); long-K ones want the deeper BK=64 step
+            if (g.ntaps == 1 && g.C <= 1024) {
+                if (n128) launch_cfg<128, 128, 2, 2, 32, 3>(x, w, y, g, stats_slab, s);
+                else launch_cfg<128, 64, 4, 1, 32, 3>(x, w, y, g, stats_slab, s);
+            } else {
+                if (n128) launch_cfg<128, 128, 2, 2, 64, 2>(x, w, y, g, stats_slab, s);
+                else launch_cfg<128, 64, 4, 1, 64, 2>(x, w, y, g, stats_slab, s);
+            }
+    }
 }
 
 }  // namespace pdt

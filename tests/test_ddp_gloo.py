@@ -46,7 +46,8 @@ def test_bucket_plan_sizes_and_order():
     order = initial_order(5)
     assert order == [4, 3, 2, 1, 0]  # reverse registration order
     b = plan_buckets(numels, order, 4, cap_bytes=3000, first_cap_bytes=600)
-    assert [s.param_indices for s in b] == [[4], [3, 2], [1, 0]]  # 128-element padding per slot
+    # slots are padded to 128 elements: 512, 2048, 1536, 1024, 512 bytes in this order
+    assert [s.param_indices for s in b] == [[4], [3], [2, 1], [0]]
     assert all(o % 128 == 0 for s in b for o in s.offsets)
     big = plan_buckets([10_000, 10], [0, 1], 4, cap_bytes=1000)
     assert [s.param_indices for s in big] == [[0], [1]]  # an oversize tensor gets its own bucket
