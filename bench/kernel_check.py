@@ -173,9 +173,13 @@ def check_bn(B, C, H, W, time_it):
         e = max(rel_err(mean, mr), rel_err(invstd, ir), rel_err(rm, rm2), rel_err(rv, rv2), float(abs(int(nbt) - int(nbt2))))
         record(f"bn_finalize {tag}", e < 1e-4, e)
         for relu, use_res in ((True, True), (True, False), (False, False), (False, True)):
-            z = native.bn_apply_act(x, mr, ir, gamma, beta, res if use_res else None, relu)
-            zr = reference.bn_apply_act(x, mr, ir, gamma, beta, res if use_res else None, relu)
+            z, act = native.bn_apply_act(x, mr, ir, gamma, beta, res if use_res else None, relu)
+            zr, _ = reference.bn_apply_act(x, mr, ir, gamma, beta, res if use_res else None, relu)
             e = rel_err(z, zr)
+            if relu:  # the bitmask must agree with the z this kernel wrote
+                bits = ((act.view(-1, C // 8, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).reshape(-1, C)
+                zf = z.permute(0, 2, 3, 1).reshape(-1, C)
+                e = max(e, float(((zf > 0) != (bits > 0)).sum()))
             extra = None
             if time_it and relu and use_res:
                 us = timeit(lambda: native.bn_apply_act(x, mr, ir, gamma, beta, res, True))
@@ -185,16 +189,16 @@ def check_bn(B, C, H, W, time_it):
     def bwd():
         st = reference.bn_stats(x)
         mean, invstd = reference.bn_finalize(st, count, 1e-5)
-        z = reference.bn_apply_act(x, mean, invstd, gamma, beta, res, True)
+        z, act = native.bn_apply_act(x, mean, invstd, gamma, beta, res, True)
         dz = nhwc(B, C, H, W)
         for relu in (True, False):
-            ps = native.bn_bwd_reduce(dz, z, x, mean, invstd, relu)
+            ps = native.bn_bwd_reduce(dz, act, x, mean, invstd, relu)
             sr = reference.bn_bwd_reduce(dz, z, x, mean, invstd, relu)
             e = rel_err(native.bn_sum_partials(ps), sr[0])
-            extra = {"us": round(timeit(lambda: native.bn_bwd_reduce(dz, z, x, mean, invstd, relu)), 1)} if time_it else None
+            extra = {"us": round(timeit(lambda: native.bn_bwd_reduce(dz, act, x, mean, invstd, relu)), 1)} if time_it else None
             record(f"bn_bwd_reduce r{int(relu)} {tag}", e < 2e-3, e, extra)
             for dres in (True, False):
-                dx, dr, sm = native.bn_bwd_elemt(dz, z, x, mean, invstd, gamma, ps, count, relu, dres)
+                dx, dr, sm = native.bn_bwd_elemt(dz, act, x, mean, invstd, gamma, ps, count, relu, dres)
                 dxr, drr, smr = reference.bn_bwd_elemt(dz, z, x, mean, invstd, gamma, sr, count, relu, dres)
                 e = max(rel_err(dx, dxr), rel_err(sm, smr))
                 if dres:

@@ -110,8 +110,15 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
 
 // wt: [Cin][KH*KW][Cout] bf16 contiguous (transpose_weight(w))
 Tensor conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_shape, int64_t KH, int64_t KW,
-                    int64_t stride, int64_t pad) {
+                    int64_t stride, int64_t pad, const c10::optional<Tensor>& addend) {
     check_nhwc_bf16(dy, "dy");
+    const void* addend_ptr = nullptr;
+    if (addend.has_value() && addend->defined()) {
+        check_nhwc_bf16(*addend, "addend");
+        TORCH_CHECK(addend->sizes().vec() == x_shape, "addend must have the shape of dx");
+        TORCH_CHECK(stride == 1, "addend fusion is implemented for stride-1 data gradients");
+        addend_ptr = addend->data_ptr();
+    }
     TORCH_CHECK(wt.is_cuda() && wt.scalar_type() == at::kBFloat16 && wt.dim() == 3 && wt.is_contiguous(),
                 "wt: expected contiguous bf16 [Cin][taps][Cout]");
     TORCH_CHECK(x_shape.size() == 4, "x_shape must be [B,C,H,W]");
@@ -144,6 +151,7 @@ Tensor conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_s
                 const int t = r * KW + q;
                 g.dh[t] = (int8_t)(pad - r); g.dw[t] = (int8_t)(pad - q); g.wslot[t] = (int8_t)t;
             }
+        g.addend = addend_ptr;
         launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, nullptr, s);
         return dx;
     }
@@ -205,6 +213,43 @@ Tensor transpose_weight(const Tensor& w) {
     Tensor wt = at::empty({C, T, N}, w.options().memory_format(at::MemoryFormat::Contiguous));
     launch_transpose_ntc(w.data_ptr(), wt.data_ptr(), (int)N, (int)T, (int)C, cur_stream(w));
     return wt;
+}
+
+// all weights of a model in ONE launch (<= 64 per launch): returns the [C][T][N] transposes
+std::vector<Tensor> transpose_weights(std::vector<Tensor> ws, c10::optional<std::vector<Tensor>> outs) {
+    std::vector<Tensor> res;
+    if (ws.empty()) return res;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(ws[0].device());
+    hipStream_t stream = cur_stream(ws[0]);
+    TransposeArgs a;
+    a.n = 0;
+    a.block_start[0] = 0;
+    for (size_t i = 0; i < ws.size(); ++i) {
+        const Tensor& w = ws[i];
+        check_conv_weight(w, "w");
+        const long N = w.size(0), C = w.size(1), T = w.size(2) * w.size(3);
+        Tensor wt;
+        if (outs.has_value()) {
+            wt = (*outs)[i];
+            TORCH_CHECK(wt.is_cuda() && wt.scalar_type() == at::kBFloat16 && wt.is_contiguous() && wt.dim() == 3 &&
+                            wt.size(0) == C && wt.size(1) == T && wt.size(2) == N,
+                        "transpose_weights: bad output buffer");
+        } else {
+            wt = at::empty({C, T, N}, w.options().memory_format(at::MemoryFormat::Contiguous));
+        }
+        res.push_back(wt);
+        a.src[a.n] = w.data_ptr();
+        a.dst[a.n] = wt.data_ptr();
+        a.N[a.n] = (int)N; a.T[a.n] = (int)T; a.C[a.n] = (int)C;
+        a.block_start[a.n + 1] = a.block_start[a.n] + (int)(((C + 31) / 32) * ((N + 31) / 32) * T);
+        if (++a.n == kTransposeMax) {
+            launch_multi_transpose(a, stream);
+            a.n = 0;
+            a.block_start[0] = 0;
+        }
+    }
+    launch_multi_transpose(a, stream);
+    return res;
 }
 
 // --------------------------------------------------------------------------------------- bn
@@ -273,8 +318,10 @@ Tensor bn_sum_partials(const Tensor& stats) {
     return out;
 }
 
-Tensor bn_apply_act(const Tensor& x, const Tensor& mean, const Tensor& invstd, const Tensor& gamma, const Tensor& beta,
-                    const c10::optional<Tensor>& residual, bool relu) {
+// -> (z, mask): mask is the 1-bit-per-element ReLU activity map [M, C/8] uint8 (undefined without relu);
+// the backward kernels read it instead of the 16x larger z
+std::tuple<Tensor, Tensor> bn_apply_act(const Tensor& x, const Tensor& mean, const Tensor& invstd, const Tensor& gamma,
+                                        const Tensor& beta, const c10::optional<Tensor>& residual, bool relu) {
     check_nhwc_bf16(x, "x");
     const long C = x.size(1), M = x.numel() / C;
     TORCH_CHECK(bn_channels_ok(C), "bn: unsupported channel count ", C);
@@ -287,10 +334,20 @@ Tensor bn_apply_act(const Tensor& x, const Tensor& mean, const Tensor& invstd, c
         res = residual->data_ptr();
     }
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
-    Tensor z = at::empty_like(x);
-    launch_bn_apply(x.data_ptr(), res, z.data_ptr(), M, (int)C, mean.data_ptr<float>(), invstd.data_ptr<float>(),
-                    gamma.data_ptr<float>(), beta.data_ptr<float>(), relu ? 1 : 0, cur_stream(x));
-    return z;
+    Tensor z = at::empty_like(x), mask;
+    if (relu) mask = at::empty({M, C / 8}, x.options().dtype(at::kByte));
+    launch_bn_apply(x.data_ptr(), res, z.data_ptr(), relu ? mask.data_ptr<uint8_t>() : nullptr, M, (int)C,
+                    mean.data_ptr<float>(), invstd.data_ptr<float>(), gamma.data_ptr<float>(), beta.data_ptr<float>(),
+                    relu ? 1 : 0, cur_stream(x));
+    return {z, mask};
+}
+
+const void* relu_mask_ptr(const c10::optional<Tensor>& mask, long M, long C) {
+    TORCH_CHECK(mask.has_value() && mask->defined(), "relu=True needs the activity mask of bn_apply_act");
+    TORCH_CHECK(mask->is_cuda() && mask->scalar_type() == at::kByte && mask->is_contiguous() &&
+                    mask->numel() == M * (C / 8),
+                "mask: expected contiguous uint8 [M, C/8]");
+    return mask->data_ptr();
 }
 
 Tensor bn_bwd_reduce(const Tensor& dz, const c10::optional<Tensor>& z, const Tensor& x, const Tensor& mean,
@@ -302,10 +359,7 @@ Tensor bn_bwd_reduce(const Tensor& dz, const c10::optional<Tensor>& z, const Ten
     check_vec_f32(mean, C, "mean"); check_vec_f32(invstd, C, "invstd");
     const void* zp = nullptr;
     if (relu) {
-        TORCH_CHECK(z.has_value() && z->defined(), "relu=True needs the forward output z");
-        check_nhwc_bf16(*z, "z");
-        TORCH_CHECK(z->sizes() == x.sizes(), "z shape mismatch");
-        zp = z->data_ptr();
+        zp = relu_mask_ptr(z, M, C);
     }
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     const int parts = bn_parts(M, (int)C);
@@ -331,10 +385,7 @@ std::tuple<Tensor, Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::opt
     TORCH_CHECK(reinterpret_cast<uintptr_t>(psums.data_ptr()) % 16 == 0 && C % 4 == 0, "psums alignment");
     const void* zp = nullptr;
     if (relu) {
-        TORCH_CHECK(z.has_value() && z->defined(), "relu=True needs the forward output z");
-        check_nhwc_bf16(*z, "z");
-        TORCH_CHECK(z->sizes() == x.sizes(), "z shape mismatch");
-        zp = z->data_ptr();
+        zp = relu_mask_ptr(z, M, C);
     }
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor dx = at::empty_like(x), dres;
@@ -596,9 +647,11 @@ void multi_flatten_tensors(std::vector<at::Tensor>& srcs, std::vector<at::Tensor
 
 void bind_ops(pybind11::module& m) {
     m.def("conv2d_fwd", &conv2d_fwd);
-    m.def("conv2d_dgrad", &conv2d_dgrad);
+    m.def("conv2d_dgrad", &conv2d_dgrad, pybind11::arg("dy"), pybind11::arg("wt"), pybind11::arg("x_shape"), pybind11::arg("kh"),
+          pybind11::arg("kw"), pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("addend") = pybind11::none());
     m.def("conv2d_wgrad", &conv2d_wgrad);
     m.def("transpose_weight", &transpose_weight);
+    m.def("transpose_weights", &transpose_weights, pybind11::arg("weights"), pybind11::arg("outs") = pybind11::none());
     m.def("bn_stats", &bn_stats);
     m.def("bn_finalize", &bn_finalize);
     m.def("bn_sum_partials", &bn_sum_partials);

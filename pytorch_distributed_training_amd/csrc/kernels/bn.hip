@@ -141,9 +141,11 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restric
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
 }
 
+// With RELU the kernel also writes one bit per element (uint8 per 8 channels): backward reads this
+// 16x smaller mask instead of re-reading the bf16 output to know where the ReLU was active.
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ x, const bf16* __restrict__ res,
-                                                       bf16* __restrict__ z, long M, int C,
+                                                       bf16* __restrict__ z, uint8_t* __restrict__ mask, long M, int C,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma,
@@ -176,15 +178,20 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ 
             for (int k = 0; k < 8; ++k) o[k] += (float)rv[k];
         }
         if (RELU) {
+            unsigned bits = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = fmaxf(o[k], 0.f);
+            for (int k = 0; k < 8; ++k) {
+                bits |= (o[k] > 0.f ? 1u : 0u) << k;
+                o[k] = fmaxf(o[k], 0.f);
+            }
+            mask[r * m.G + m.cg] = (uint8_t)bits;
         }
         st8(z + off, o);
     }
 }
 
 template <bool RELU>
-__global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const bf16* __restrict__ dz, const bf16* __restrict__ z,
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const bf16* __restrict__ dz, const uint8_t* __restrict__ mask,
                                                             const bf16* __restrict__ x, long M, int C,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
@@ -200,12 +207,12 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const bf16* __restri
         const long off = r * C + m.cg * 8;
         const bf16x8 g = ld8(dz + off);
         const bf16x8 xv = ld8(x + off);
-        bf16x8 zv;
-        if (RELU) zv = ld8(z + off);
+        unsigned bits = 0xffu;
+        if (RELU) bits = mask[r * m.G + m.cg];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float gg = (float)g[k];
-            if (RELU) gg = ((float)zv[k] > 0.f) ? gg : 0.f;
+            if (RELU) gg = ((bits >> k) & 1u) ? gg : 0.f;
             s0[k] += gg;
             s1[k] += gg * ((float)xv[k] - mu[k]) * is[k];
         }
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const bf16* __restri
 
 // dx = k1*dzm + k2*x + k3 with per-channel k's (see host comment); dres = dzm
 template <bool RELU, bool DRES>
-__global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restrict__ dz, const bf16* __restrict__ z,
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restrict__ dz, const uint8_t* __restrict__ mask,
                                                            const bf16* __restrict__ x, bf16* __restrict__ dx,
                                                            bf16* __restrict__ dres, long M, int C,
                                                            const float* __restrict__ mean,
@@ -265,13 +272,13 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
         const long off = r * C + m.cg * 8;
         const bf16x8 g = ld8(dz + off);
         const bf16x8 xv = ld8(x + off);
-        bf16x8 zv;
-        if (RELU) zv = ld8(z + off);
+        unsigned bits = 0xffu;
+        if (RELU) bits = mask[r * m.G + m.cg];
         float o[8], gm[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float gg = (float)g[k];
-            if (RELU) gg = ((float)zv[k] > 0.f) ? gg : 0.f;
+            if (RELU) gg = ((bits >> k) & 1u) ? gg : 0.f;
             gm[k] = gg;
             o[k] = k1[k] * gg + k2[k] * (float)xv[k] + k3[k];
         }
@@ -304,7 +311,7 @@ void launch_bn_finalize(const float* stats, int nparts, int C, float count, cons
                        eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd, sums_out);
 }
 
-void launch_bn_apply(const void* x, const void* residual, void* z, long M, int C, const float* mean,
+void launch_bn_apply(const void* x, const void* residual, void* z, uint8_t* mask, long M, int C, const float* mean,
                      const float* invstd, const float* gamma, const float* beta, int relu, hipStream_t s) {
     const int R = kThreads / (C >> 3);
     long blocks = (M + (long)R * 8 - 1) / ((long)R * 8);
@@ -313,7 +320,7 @@ void launch_bn_apply(const void* x, const void* residual, void* z, long M, int C
     dim3 grid((int)blocks), block(kThreads);
 #define PDT_APPLY(RELU, RES)                                                                                    \
     hipLaunchKernelGGL((k_bn_apply<RELU, RES>), grid, block, 0, s, (const bf16*)x, (const bf16*)residual, (bf16*)z, \
-                       M, C, mean, invstd, gamma, beta)
+                       mask, M, C, mean, invstd, gamma, beta)
     if (relu && residual) PDT_APPLY(true, true);
     else if (relu) PDT_APPLY(true, false);
     else if (residual) PDT_APPLY(false, true);
@@ -326,10 +333,10 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, 
     const size_t lds = (size_t)kThreads * 16 * sizeof(float);
     if (relu)
         hipLaunchKernelGGL((k_bn_bwd_reduce<true>), dim3(parts), dim3(kThreads), lds, s, (const bf16*)dz,
-                           (const bf16*)z, (const bf16*)x, M, C, mean, invstd, slab);
+                           (const uint8_t*)z, (const bf16*)x, M, C, mean, invstd, slab);
     else
         hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(parts), dim3(kThreads), lds, s, (const bf16*)dz,
-                           (const bf16*)z, (const bf16*)x, M, C, mean, invstd, slab);
+                           (const uint8_t*)z, (const bf16*)x, M, C, mean, invstd, slab);
 }
 
 void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx, void* dres, long M, int C,
@@ -341,7 +348,7 @@ void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx,
     if (blocks < 1) blocks = 1;
     dim3 grid((int)blocks), block(kThreads);
 #define PDT_ELEMT(RELU, DRES)                                                                                  \
-    hipLaunchKernelGGL((k_bn_bwd_elemt<RELU, DRES>), grid, block, 0, s, (const bf16*)dz, (const bf16*)z,       \
+    hipLaunchKernelGGL((k_bn_bwd_elemt<RELU, DRES>), grid, block, 0, s, (const bf16*)dz, (const uint8_t*)z,       \
                        (const bf16*)x, (bf16*)dx, (bf16*)dres, M, C, mean, invstd, gamma, psums, nps, sums_out, count,   \
                        count_dev)
     if (relu && dres) PDT_ELEMT(true, true);

@@ -249,7 +249,12 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                 const long b = t1 / g.nOH;
                 pix = (b * g.Hout + (i * g.os + g.ooh)) * g.Wout + (j * g.os + g.oow);
             }
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * OPITCH + och * 16);
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * OPITCH + och * 16);
+            if (g.addend != nullptr) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.addend) + pix * g.N + ncol);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)a[k]);
+            }
             *reinterpret_cast<bf16x8*>(y + pix * g.N + ncol) = v;
         }
     }

@@ -245,6 +245,37 @@ __global__ __launch_bounds__(256) void k_transpose_ntc(const bf16* __restrict__ 
     }
 }
 
+// Many weights at once: w_i [N][T][C] -> wt_i [C][T][N], table in the kernel arguments.  One launch
+// per optimizer step refreshes every transposed conv weight the dgrad kernels read.
+__global__ __launch_bounds__(256) void k_multi_transpose_ntc(const TransposeArgs a) {
+    __shared__ bf16 tile[32][34];
+    int lo = 0, hi = a.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.block_start[mid] <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const bf16* w = static_cast<const bf16*>(a.src[lo]);
+    bf16* wt = static_cast<bf16*>(a.dst[lo]);
+    const int N = a.N[lo], T = a.T[lo], C = a.C[lo];
+    int b = (int)blockIdx.x - a.block_start[lo];
+    const int ct = (C + 31) / 32, nt = (N + 31) / 32;
+    const int c0 = (b % ct) * 32;
+    b /= ct;
+    const int n0 = (b % nt) * 32;
+    const int t = b / nt;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, c = c0 + tx;
+        tile[r][tx] = (n < N && c < C) ? w[((long)n * T + t) * C + c] : (bf16)0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, n = n0 + tx;
+        if (n < N && c < C) wt[((long)c * T + t) * N + n] = tile[tx][r];
+    }
+}
+
 // out[y][j] = sum over the parts of chunk y of slab[p*stride + j].  Block = 64 column quads x 4
 // part lanes; grid = (column blocks of 256, part chunks).  Deterministic (no atomics).
 __global__ __launch_bounds__(256) void k_reduce_slab(const float* __restrict__ slab, int nparts, long stride, int n,
@@ -345,6 +376,11 @@ void launch_to_nhwc_bf16(const void* src, int src_dtype, void* dst, int B, int C
 void launch_transpose_ntc(const void* w, void* wt, int N, int T, int C, hipStream_t s) {
     dim3 grid((C + 31) / 32, (N + 31) / 32, T);
     hipLaunchKernelGGL(k_transpose_ntc, grid, dim3(256), 0, s, (const bf16*)w, (bf16*)wt, N, T, C);
+}
+
+void launch_multi_transpose(const TransposeArgs& a, hipStream_t s) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(k_multi_transpose_ntc, dim3(a.block_start[a.n]), dim3(256), 0, s, a);
 }
 
 void launch_reduce_slab(const float* slab, int nparts, long stride, int n, float* out, float* tmp,

@@ -37,6 +37,15 @@ void launch_to_nhwc_bf16(const void* src, int src_dtype, void* dst, int B, int C
                          hipStream_t s);
 // w [N][T][C] -> wt [C][T][N]  (bf16)
 void launch_transpose_ntc(const void* w, void* wt, int N, int T, int C, hipStream_t s);
+constexpr int kTransposeMax = 64;
+struct TransposeArgs {
+    const void* src[kTransposeMax];
+    void* dst[kTransposeMax];
+    int N[kTransposeMax], T[kTransposeMax], C[kTransposeMax];
+    int block_start[kTransposeMax + 1];  // prefix sums of 32x32-tile blocks
+    int n;
+};
+void launch_multi_transpose(const TransposeArgs& a, hipStream_t s);
 // out[j] = sum_p slab[p*stride + j], j < n  (fp32, deterministic).  tmp: fp32 [kReduceChunks][n]
 // workspace, required when nparts > 64 (two-level reduction).
 constexpr int kReduceChunks = 32;
@@ -56,7 +65,8 @@ void launch_bn_stats(const void* x, long M, int C, float* slab /*[parts][2][C]*/
 void launch_bn_finalize(const float* stats, int nparts, int C, float count, const float* count_dev, float eps,
                         float momentum, float* running_mean, float* running_var, long* num_batches_tracked,
                         float* mean, float* invstd, float* sums_out, hipStream_t s);
-void launch_bn_apply(const void* x, const void* residual, void* z, long M, int C, const float* mean,
+// relu: also writes the 1-bit-per-element activity mask [M][C/8] that the backward kernels take as `z`
+void launch_bn_apply(const void* x, const void* residual, void* z, uint8_t* mask, long M, int C, const float* mean,
                      const float* invstd, const float* gamma, const float* beta, int relu, hipStream_t s);
 void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, int C, const float* mean,
                           const float* invstd, int relu, float* slab /*[parts][2][C]*/, int parts,
@@ -86,6 +96,9 @@ struct ConvGeom {
     int ntaps;        // taps of this launch
     int wtaps;        // T of the weight tensor [N][wtaps][C]
     int8_t dh[kMaxTaps], dw[kMaxTaps], wslot[kMaxTaps];
+    // optional bf16 tensor with the output's shape that is added in the epilogue (fuses the residual
+    // branch's gradient into the data-gradient kernel instead of a separate elementwise add)
+    const void* addend;
 };
 // y = conv(x, w); when stats_slab != nullptr also writes per-(m-tile) partial [sum, sum_sq] rows
 // stats_slab[m_tile][2][N] computed from the bf16-rounded outputs.

@@ -45,10 +45,11 @@ class BasicBlock(tnn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x
-        out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
         if self.downsample is not None:
+            out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
             identity = conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        else:  # identity branch routed through conv1's node: its gradient is fused into conv1's dgrad
+            out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, return_skip=True)
         return conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=identity)
 
 
@@ -68,11 +69,12 @@ class Bottleneck(tnn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x
-        out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
         if self.downsample is not None:
+            out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
             identity = conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        else:  # identity branch routed through conv1's node: its gradient is fused into conv1's dgrad
+            out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, return_skip=True)
+        out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
         return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=identity)
 
 

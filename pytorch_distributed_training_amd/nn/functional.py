@@ -44,8 +44,12 @@ def _cl(t: torch.Tensor) -> torch.Tensor:
 
 # --------------------------------------------------------------------- conv
 class _Conv2dFn(torch.autograd.Function):
+    """``(y, stats, skip)``: ``skip`` (when requested) is the input passed through, to be used as the
+    residual branch of the block.  Its gradient then arrives HERE and is added inside the data-gradient
+    kernel's epilogue, instead of autograd summing two activation-sized tensors with a separate add."""
+
     @staticmethod
-    def forward(ctx, x, w, w_lp, stride, padding, want_stats):
+    def forward(ctx, x, w, w_lp, stride, padding, want_stats, with_skip):
         wk = w_lp if w_lp is not None else w
         be = backend_for(x)
         x = _cl(x)
@@ -54,38 +58,40 @@ class _Conv2dFn(torch.autograd.Function):
             if why is not None:
                 _note_fallback("conv2d", why)
                 be = reference
+                want_stats = False  # the BN node's native one-pass bn_stats beats torch reductions over y
         y, stats = be.conv2d_fwd(x, wk, stride, padding, want_stats)
         ctx.set_materialize_grads(False)  # no zero-filled gradient for the (non-differentiable) stats output
         ctx.save_for_backward(x, wk)
         ctx.cfg = (be, stride, padding, tuple(w.shape), w.dtype)
         if stats is not None:
             ctx.mark_non_differentiable(stats)
-        return y, stats
+        return y, stats, (x.view_as(x) if with_skip else None)
 
     @staticmethod
-    def backward(ctx, dy, _dstats):
+    def backward(ctx, dy, _dstats, dskip):
         x, wk = ctx.saved_tensors
         be, stride, padding, w_shape, w_dtype = ctx.cfg
-        if dy is None:
-            return None, None, None, None, None, None
-        dy = _cl(dy)
         dx = dw = None
+        if dy is None:
+            return dskip, None, None, None, None, None, None
+        dy = _cl(dy)
         if ctx.needs_input_grad[0]:
-            dx = be.conv2d_dgrad(dy, wk, tuple(x.shape), stride, padding)
+            dx = be.conv2d_dgrad(dy, wk, tuple(x.shape), stride, padding, None if dskip is None else _cl(dskip))
         if ctx.needs_input_grad[1]:
             dw = be.conv2d_wgrad(dy, x, w_shape, stride, padding)
             if dw.dtype != w_dtype:
                 dw = dw.to(w_dtype)
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
-def conv2d(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = False):
-    """Bias-free square-stride conv.  Returns ``(y, stats)`` where ``stats`` is the
-    fp32 partial rows ``[P, 2, Cout]`` of the per-channel ``[sum, sum_sq]`` of ``y`` (or ``None``)."""
+def conv2d(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = False, with_skip: bool = False):
+    """Bias-free square-stride conv.  Returns ``(y, stats)`` (+ ``skip`` when ``with_skip``) where ``stats``
+    is the fp32 partial rows ``[P, 2, Cout]`` of the per-channel ``[sum, sum_sq]`` of ``y`` (or ``None``)."""
     w_lp = getattr(weight, "_lp", None)
     if w_lp is not None and w_lp.dtype != x.dtype:
         w_lp = None
-    return _Conv2dFn.apply(x, weight, w_lp, int(stride), int(padding), bool(want_stats))
+    y, stats, skip = _Conv2dFn.apply(x, weight, w_lp, int(stride), int(padding), bool(want_stats), bool(with_skip))
+    return (y, stats, skip) if with_skip else (y, stats)
 
 
 # ---------------------------------------------------------------- batchnorm
@@ -149,8 +155,8 @@ class _BNActFn(torch.autograd.Function):
             invstd = torch.rsqrt(cfg.running_var.float() + cfg.eps)
         g32 = gamma.float() if gamma is not None else torch.ones(c, device=x.device)
         b32 = beta.float() if beta is not None else torch.zeros(c, device=x.device)
-        z = be.bn_apply_act(x, mean, invstd, g32, b32, residual, relu)
-        ctx.save_for_backward(x, z if relu else None, mean, invstd, g32, count_t)
+        z, act = be.bn_apply_act(x, mean, invstd, g32, b32, residual, relu)
+        ctx.save_for_backward(x, act if relu else None, mean, invstd, g32, count_t)
         ctx.cfg = (be, cfg, relu, world, count, residual is not None,
                    None if gamma is None else gamma.dtype, None if beta is None else beta.dtype)
         return z
@@ -252,14 +258,18 @@ def softmax_cross_entropy(logits, labels):
 
 
 # ------------------------------------------------------------------ helpers
-def conv_bn_act(x, conv, bn, relu: bool = True, residual=None):
+def conv_bn_act(x, conv, bn, relu: bool = True, residual=None, return_skip: bool = False):
     """``act(bn(conv(x)) [+ residual])`` through the fused nodes.
 
-    ``conv``/``bn`` are modules (parameter containers); bias-free square convs
-    with dilation 1 and groups 1 take the fused path, anything else falls back
-    to the module's own forward.
+    ``conv``/``bn`` are modules (parameter containers); bias-free square convs with dilation 1 and
+    groups 1 take the fused path, anything else falls back to the module's own forward.
+    ``return_skip=True`` also returns ``x`` routed through the conv node (use it as the block's
+    identity branch so its gradient is fused into this conv's data-gradient kernel).
     """
     from .modules import BatchNorm2d, Conv2d  # local: avoid cycle
+
+    def done(out, skip):
+        return (out, skip) if return_skip else out
 
     if _PLAIN_TORCH:
         # calibration mode: the same network through stock PyTorch-ROCm ops (MIOpen conv, ATen BN)
@@ -271,7 +281,7 @@ def conv_bn_act(x, conv, bn, relu: bool = True, residual=None):
                                            bn.momentum if bn.momentum is not None else 0.1, bn.eps)
         if residual is not None:
             y = y + residual
-        return torch.relu(y) if relu else y
+        return done(torch.relu(y) if relu else y, x)
 
     fusable = (
         isinstance(conv, Conv2d) and isinstance(bn, BatchNorm2d) and conv.bias is None and conv.groups == 1
@@ -282,7 +292,11 @@ def conv_bn_act(x, conv, bn, relu: bool = True, residual=None):
         y = bn(conv(x))
         if residual is not None:
             y = y + residual
-        return torch.relu(y) if relu else y
+        return done(torch.relu(y) if relu else y, x)
     want_stats = bn.training or not bn.track_running_stats
-    y, stats = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats)
-    return bn(y, residual=residual, relu=relu, stats=stats)
+    skip = x
+    if return_skip and torch.is_grad_enabled() and x.requires_grad:
+        y, stats, skip = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats, with_skip=True)
+    else:
+        y, stats = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats)
+    return done(bn(y, residual=residual, relu=relu, stats=stats), skip)

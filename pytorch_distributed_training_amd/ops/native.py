@@ -52,15 +52,51 @@ def _w_cl(w):
 
 
 # --------------------------------------------------------------------- conv
+# Transposed weights ([Cin][taps][Cout]) for the data-gradient GEMM.  Parameters' bf16 working copies are
+# long-lived tensors that only change in optimizer.step() / load_state_dict, so their transposes are
+# cached per "weights epoch" and ALL refreshed by one multi-tensor launch at the first dgrad of a step.
+_weights_epoch = 0
+_wt_registry: dict[int, list] = {}  # id(w) -> [w, wt, epoch]
+
+
+def bump_weights_epoch() -> None:
+    """Call whenever parameter values changed (optimizer step, checkpoint load)."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _register_weight(w) -> None:
+    if getattr(w, "_pdt_param", False) and id(w) not in _wt_registry:
+        _wt_registry[id(w)] = [w, None, -1]
+
+
+def _transposed(w):
+    if not getattr(w, "_pdt_param", False):
+        return _C.transpose_weight(_w_cl(w))
+    ent = _wt_registry.get(id(w))
+    if ent is None:
+        ent = _wt_registry[id(w)] = [w, None, -1]
+    if ent[2] != _weights_epoch:
+        stale = [e for e in _wt_registry.values() if e[2] != _weights_epoch and e[0].device == w.device]
+        have = all(e[1] is not None for e in stale)
+        outs = _C.transpose_weights([e[0] for e in stale], [e[1] for e in stale] if have else None)
+        for e, o in zip(stale, outs):
+            e[1], e[2] = o, _weights_epoch
+    return ent[1]
+
+
 def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False):
+    _register_weight(w)
     y, stats = _C.conv2d_fwd(x, _w_cl(w), stride, padding, want_stats)
     return y, (stats if want_stats else None)
 
 
-def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int):
+def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None):
     kh, kw = w.shape[2], w.shape[3]
-    wt = _C.transpose_weight(_w_cl(w))  # [Cin][taps][Cout]: K-contiguous operand for the dgrad GEMM
-    return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding)
+    wt = _transposed(w)  # [Cin][taps][Cout]: K-contiguous operand for the dgrad GEMM
+    if addend is not None and stride != 1:
+        return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, None) + addend
+    return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend)
 
 
 def conv2d_wgrad(dy, x, w_shape, stride: int, padding: int):
@@ -93,6 +129,7 @@ def bn_finalize(stats, count, eps: float, running_mean=None, running_var=None, m
 
 
 def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False):
+    """-> (z, act): ``act`` is the uint8 [M, C/8] ReLU bitmask the backward kernels read (None without relu)"""
     return _C.bn_apply_act(x, mean, invstd, gamma.contiguous(), beta.contiguous(), residual, relu)
 
 
@@ -169,9 +206,11 @@ def multi_adam(params, grads, ms, vs, lps, lr, beta1, beta2, eps, weight_decay, 
     if not ok:
         for p, g, m, v, lp in zip(params, grads, ms, vs, lps):
             reference.adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, float(step), adamw, grad_scale, lp)
+        bump_weights_epoch()
         return
     _C.multi_adam(list(params), list(grads), list(ms), list(vs), list(lps), lr, beta1, beta2, eps, weight_decay,
                   int(step), bool(adamw), grad_scale)
+    bump_weights_epoch()
 
 
 def multi_sgd(params, grads, bufs, lps, lr, momentum, dampening, weight_decay, nesterov, first, grad_scale=1.0):
@@ -180,6 +219,8 @@ def multi_sgd(params, grads, bufs, lps, lr, momentum, dampening, weight_decay, n
     if not ok:
         for p, g, b, lp in zip(params, grads, bufs, lps):
             reference.sgd_step(p, g, b, lr, momentum, dampening, weight_decay, nesterov, first, grad_scale, lp)
+        bump_weights_epoch()
         return
     _C.multi_sgd(list(params), list(grads), list(bufs), list(lps), lr, momentum, dampening, weight_decay,
                  bool(nesterov), bool(first), grad_scale)
+    bump_weights_epoch()

@@ -23,7 +23,12 @@ def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False):
     return y, None
 
 
-def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int):
+def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None):
+    dx = _conv2d_dgrad(dy, w, x_shape, stride, padding)
+    return dx if addend is None else dx + addend
+
+
+def _conv2d_dgrad(dy, w, x_shape, stride: int, padding: int):
     return torch.ops.aten.convolution_backward(
         dy, torch.empty(x_shape, dtype=dy.dtype, device=dy.device).expand(x_shape), w.to(dy.dtype), None,
         [stride, stride], [padding, padding], [1, 1], False, [0, 0], 1, [True, False, False])[0]
@@ -71,7 +76,9 @@ def bn_finalize(stats, count, eps: float, running_mean=None, running_var=None, m
 
 
 def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False):
-    """``z = act((x-mean)*invstd*gamma + beta [+ residual])`` in the input dtype."""
+    """``z = act((x-mean)*invstd*gamma + beta [+ residual])`` in the input dtype -> ``(z, act)`` where
+    ``act`` is what the backward ops take to gate the ReLU (here ``z`` itself; the HIP path hands out a
+    1-bit-per-element mask instead)."""
     a = (invstd * gamma).view(1, -1, 1, 1)
     b = (beta - mean * invstd * gamma).view(1, -1, 1, 1)
     z = x.float() * a + b
@@ -79,7 +86,8 @@ def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False
         z = z + residual.float()
     if relu:
         z = z.clamp_min_(0.0)
-    return z.to(x.dtype)
+    z = z.to(x.dtype)
+    return z, (z if relu else None)
 
 
 def bn_bwd_reduce(dz, z, x, mean, invstd, relu: bool):

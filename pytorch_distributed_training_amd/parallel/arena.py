@@ -105,6 +105,7 @@ class ParamArena:
             dt, s = self.slots[n]
             if dt == torch.float32:
                 p._lp = _view(lp, s)
+                p._lp._pdt_param = True  # long-lived: lets the op layer cache derived layouts per step
 
     @torch.no_grad()
     def refresh_lowp(self) -> None:
@@ -112,6 +113,10 @@ class ParamArena:
         this is for loads / manual weight edits)."""
         for dt, lp in self.lowp.items():
             lp.copy_(self.by_dtype[dt])
+        if self.lowp and self.device.type == "cuda":
+            from ..ops import native
+
+            native.bump_weights_epoch()
 
     def flat_tensors(self) -> list[torch.Tensor]:
         return list(self.by_dtype.values())
