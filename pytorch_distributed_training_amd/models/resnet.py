@@ -45,11 +45,11 @@ class BasicBlock(tnn.Module):
         self.stride = stride
 
     def forward(self, x):
+        # the block input's second consumer is routed through conv1's node: that branch's gradient is
+        # then added inside conv1's data-gradient epilogue instead of by a separate elementwise kernel
+        out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, return_skip=True)
         if self.downsample is not None:
-            out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
-            identity = conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
-        else:  # identity branch routed through conv1's node: its gradient is fused into conv1's dgrad
-            out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, return_skip=True)
+            identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False)
         return conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=identity)
 
 
@@ -69,11 +69,11 @@ class Bottleneck(tnn.Module):
         self.stride = stride
 
     def forward(self, x):
+        # the block input's second consumer is routed through conv1's node: that branch's gradient is
+        # then added inside conv1's data-gradient epilogue instead of by a separate elementwise kernel
+        out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, return_skip=True)
         if self.downsample is not None:
-            out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
-            identity = conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
-        else:  # identity branch routed through conv1's node: its gradient is fused into conv1's dgrad
-            out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, return_skip=True)
+            identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False)
         out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
         return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=identity)
 
