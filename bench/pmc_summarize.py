@@ -1,0 +1,45 @@
+"""Aggregate rocprofv3 --pmc passes (bench/pmc_profile.sh) into a per-kernel table:
+MFMA busy share, LDS bank-conflict share, HBM bytes fetched / written per launch."""
+import collections
+import csv
+import glob
+import os
+import re
+import sys
+
+root = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+calls = collections.defaultdict(set)
+
+
+def short(name):
+    name = name.replace("pdt::(anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+    name = re.sub(r"\(.*", "", name)
+    m = re.match(r"_ZN3pdt12_GLOBAL__N_1\d+(k_[a-z_0-9]+?)I(.*?)E+v", name)
+    if m:
+        name = f"{m.group(1)}<{m.group(2)}>"
+    return name[:70]
+
+
+for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
+    with open(path, newline="") as fh:
+        for row in csv.DictReader(fh):
+            k = short(row["Kernel_Name"])
+            agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            calls[k].add((os.path.dirname(path), row.get("Dispatch_Id")))
+passes = max(1, len({p for s in calls.values() for p, _ in s}))
+print("| kernel | launches | MFMA busy % of SIMD cycles while the kernel runs | MFMA bf16 MOPS/launch | LDS conflict cycles / LDS active | "
+      "HBM fetch MB/launch | HBM write MB/launch |")
+print("|---|---|---|---|---|---|---|")
+rows = []
+for k, c in agg.items():
+    n = max(1, len(calls[k]) // passes)
+    gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+    mfma = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+    # SQ counters are summed over shader engines; MFMA busy is counted per SIMD-cycle (4 SIMDs x 256 CUs)
+    util = 100.0 * mfma / (gui / 8.0 * 256 * 4) if gui else 0.0  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    lds = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else 0.0
+    rows.append((gui, k, n, util, c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / n, lds,
+                 c.get("FETCH_SIZE", 0.0) / n / 1024.0, c.get("WRITE_SIZE", 0.0) / n / 1024.0))
+for gui, k, n, util, mops, lds, f, w in sorted(rows, reverse=True)[:40]:
+    print(f"| {k} | {n} | {util:.1f} | {mops:.3g} | {lds:.3f} | {f:.1f} | {w:.1f} |")
