@@ -147,6 +147,44 @@ def check_conv(args, time_it):
     run_case(f"conv_wgrad {tag}", wgrad)
 
 
+def check_stem(B, H, W, time_it):
+    """7x7 / 2 / pad 3 on 3 channels: packed-image forward (+BN statistics) and window weight gradient."""
+    tag = f"B{B} 3->64 {H}x{W} k7 s2 p3"
+    x = nhwc(B, 3, H, W)
+    w = (torch.randn(64, 3, 7, 7, device=DEV) * (1.0 / 147 ** 0.5)).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    dy = nhwc(B, 64, H // 2, W // 2)
+
+    def fwd():
+        assert native.conv_unsupported_reason(x, w, 2, 3) is None
+        y, st, xp = native.conv2d_fwd(x, w, 2, 3, True, True)
+        yr, _ = reference.conv2d_fwd(x.float(), w.float(), 2, 3, False)
+        e = rel_err(y, yr)
+        es = rel_err(reference.bn_sum_partials(st), reference.bn_stats(y)[0])
+        extra = {"stats_err": es}
+        if time_it:
+            us = timeit(lambda: native.conv2d_fwd(x, w, 2, 3, True))
+            us_lib = timeit(lambda: torch.nn.functional.conv2d(x, w, None, 2, 3))
+            extra.update({"us": round(us, 1), "us_miopen": round(us_lib, 1)})
+        record(f"stem_fwd   {tag}", e < 2e-2 and es < 2e-2, e, extra)
+
+    def wgrad():
+        xp = native.conv2d_fwd(x, w, 2, 3, False, True)[2]
+        dw = native.conv2d_wgrad(dy, xp, (64, 3, 7, 7), 2, 3)
+        dw2 = native.conv2d_wgrad(dy, x, (64, 3, 7, 7), 2, 3)  # packs by itself
+        dwr = reference.conv2d_wgrad(dy.float(), x.float(), (64, 3, 7, 7), 2, 3)
+        e = max(rel_err(dw, dwr), rel_err(dw2, dwr))
+        extra = {}
+        if time_it:
+            us = timeit(lambda: native.conv2d_wgrad(dy, xp, (64, 3, 7, 7), 2, 3))
+            us_lib = timeit(lambda: reference.conv2d_wgrad(dy, x, (64, 3, 7, 7), 2, 3))
+            extra.update({"us": round(us, 1), "us_miopen": round(us_lib, 1)})
+        record(f"stem_wgrad {tag}", e < 2e-2, e, extra)
+
+    run_case(f"stem_fwd {tag}", fwd)
+    run_case(f"stem_wgrad {tag}", wgrad)
+
+
 # -------------------------------------------------------------------------------- bn
 def check_bn(B, C, H, W, time_it):
     tag = f"B{B} C{C} {H}x{W}"
@@ -322,6 +360,9 @@ def main():
             shapes += [(128, 64, 56, 56), (128, 256, 56, 56), (128, 512, 28, 28), (128, 2048, 7, 7)]
         for s in shapes:
             check_bn(*s, a.time)
+    if only is None or "stem" in only:
+        for shp in ((2, 32, 32), (3, 64, 48)) + (() if a.quick else ((128, 224, 224),)):
+            check_stem(*shp, a.time)
     if only is None or "conv" in only:
         for c in conv_cases(a.quick):
             check_conv(c, a.time)

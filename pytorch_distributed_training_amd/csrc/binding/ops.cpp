@@ -12,6 +12,9 @@
 #include <unordered_map>
 
 #include "../kernels/kernels.h"
+#include <cstdlib>
+#include <string>
+
 #include "binding.h"
 
 namespace pdt {
@@ -186,6 +189,17 @@ Tensor conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_s
     return dx;
 }
 
+bool wgrad_win_enabled() {
+    static const bool on = [] {
+        // measured on MI355X (profiles/r1_wgrad_win_vs_tap.md): with three taps per wave the window kernel's
+        // per-chunk index math outweighs its MFMA work and the per-tap kernel wins on every ResNet 3x3
+        // shape, so it is opt-in for convs (the packed stem always uses it: nothing else fits K = 147)
+        const char* e = std::getenv("PDT_WGRAD_WIN");
+        return e && std::string(e) == "1";
+    }();
+    return on;
+}
+
 Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, int64_t stride, int64_t pad) {
     check_nhwc_bf16(dy, "dy");
     check_nhwc_bf16(x, "x");
@@ -196,6 +210,17 @@ Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, i
     TORCH_CHECK(C % 64 == 0 && N % 64 == 0, "conv2d_wgrad: channels must be multiples of 64");
     TORCH_CHECK((long)B * Ho * Wo < (1L << 31), "too many output pixels");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    const long wsize_all = N * KH * KW * C;
+    if (KH == 3 && KW == 3 && wgrad_win_enabled()) {  // all nine taps per workgroup from one staged window
+        WinGeom wg{(int)B, (int)Ho, (int)Wo, (int)N, (int)H, (int)W, (int)C, (int)C, 3, 3,
+                   (int)stride, (int)stride, (int)pad, (int)pad, 0, 0, 0};
+        if (wgrad_win_plan(wg)) {
+            Tensor slab = at::empty({wg.splits, wsize_all}, x.options().dtype(at::kFloat));
+            launch_wgrad_win(dy.data_ptr(), x.data_ptr(), slab.data_ptr<float>(), wg, cur_stream(x));
+            Tensor flat = wg.splits == 1 ? slab.view({wsize_all}) : reduce_slab(slab, wg.splits, wsize_all);
+            return flat.view({N, KH, KW, C}).permute({0, 3, 1, 2});
+        }
+    }
     WgradGeom g{(int)B, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, (int)N, (int)KH, (int)KW, (int)stride, (int)pad, 1};
     g.splits = conv_wgrad_splits(g);
     const long wsize = N * KH * KW * C;
@@ -204,6 +229,70 @@ Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, i
     Tensor flat = g.splits == 1 ? slab.view({wsize}) : reduce_slab(slab, g.splits, wsize);
     // physical [N][KH][KW][C] == logical [N,C,KH,KW] in channels_last
     return flat.view({N, KH, KW, C}).permute({0, 3, 1, 2});
+}
+
+// ---- 3-channel stem: 7x7 / stride 2 / pad 3 on the packed image (conv_stem.hip) ---------------------
+// -> (y, stats, xp): xp is the packed input the weight gradient reads (saved instead of x)
+std::tuple<Tensor, Tensor, Tensor> conv_stem_fwd(const Tensor& x, const Tensor& w, bool want_stats) {
+    check_nhwc_bf16(x, "x");
+    check_conv_weight(w, "w");
+    const long B = x.size(0), H = x.size(2), W = x.size(3), N = w.size(0);
+    TORCH_CHECK(x.size(1) == 3 && w.size(1) == 3 && w.size(2) == 7 && w.size(3) == 7, "conv_stem_fwd: 7x7 conv on 3 channels");
+    TORCH_CHECK(N % 64 == 0, "conv_stem_fwd: Cout must be a multiple of 64");
+    TORCH_CHECK(H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2, "conv_stem_fwd: even input size expected");
+    const long Hp = H + 6, Wp = W + 8, Ho = H / 2, Wo = W / 2;
+    TORCH_CHECK(B * Hp * Wp * 8 < (1L << 31) && B * Ho * Wo * N * 2 < (1L << 31), "stem tensors exceed 2 GiB");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    hipStream_t s = cur_stream(x);
+    Tensor xp = at::empty({B, Hp, Wp, 4}, x.options().memory_format(at::MemoryFormat::Contiguous));
+    Tensor wp = at::empty({N, 7, 32}, x.options().memory_format(at::MemoryFormat::Contiguous));
+    launch_stem_pack_x(x.data_ptr(), xp.data_ptr(), (int)B, (int)H, (int)W, s);
+    launch_stem_pack_w(w.data_ptr(), wp.data_ptr(), (int)N, s);
+    Tensor y = empty_nhwc(B, N, Ho, Wo, x);
+    ConvGeom g;
+    std::memset(&g, 0, sizeof(g));
+    g.B = B; g.Hin = Hp; g.Win = Wp; g.C = 32; g.pix_elems = 4; g.Hout = Ho; g.Wout = Wo; g.N = N;
+    g.nOH = Ho; g.nOW = Wo; g.os = 1; g.is = 2; g.ntaps = 7; g.wtaps = 7;
+    for (int t = 0; t < 7; ++t) { g.dh[t] = (int8_t)t; g.dw[t] = 0; g.wslot[t] = (int8_t)t; }
+    Tensor stats, slab;
+    float* slab_ptr = nullptr;
+    const int m_tiles = conv_igemm_m_tiles(g, nullptr);
+    if (want_stats) {
+        slab = at::empty({m_tiles, 2 * N}, x.options().dtype(at::kFloat));
+        slab_ptr = slab.data_ptr<float>();
+    }
+    launch_conv_igemm(xp.data_ptr(), wp.data_ptr(), y.data_ptr(), g, slab_ptr, s);
+    if (want_stats) stats = shrink_rows(slab, m_tiles, 2 * N, kMaxFinalizeRows).view({-1, 2, N});
+    return {y, stats, xp};
+}
+
+Tensor stem_pack_x(const Tensor& x) {
+    check_nhwc_bf16(x, "x");
+    const long B = x.size(0), H = x.size(2), W = x.size(3);
+    TORCH_CHECK(x.size(1) == 3 && H % 2 == 0 && W % 2 == 0, "stem_pack_x: [B,3,H,W] with even H, W");
+    TORCH_CHECK(B * (H + 6) * (W + 8) * 8 < (1L << 31), "packed stem input exceeds 2 GiB");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    Tensor xp = at::empty({B, H + 6, W + 8, 4}, x.options().memory_format(at::MemoryFormat::Contiguous));
+    launch_stem_pack_x(x.data_ptr(), xp.data_ptr(), (int)B, (int)H, (int)W, cur_stream(x));
+    return xp;
+}
+
+// dy [B,64,Ho,Wo] NHWC, xp from conv_stem_fwd -> dW logical [64,3,7,7] (channels_last, fp32)
+Tensor conv_stem_wgrad(const Tensor& dy, const Tensor& xp) {
+    check_nhwc_bf16(dy, "dy");
+    TORCH_CHECK(xp.is_cuda() && xp.scalar_type() == at::kBFloat16 && xp.dim() == 4 && xp.is_contiguous() && xp.size(3) == 4,
+                "xp: expected the packed stem input [B, H+6, W+8, 4]");
+    const long B = dy.size(0), N = dy.size(1), Ho = dy.size(2), Wo = dy.size(3);
+    const long Hp = xp.size(1), Wp = xp.size(2);
+    TORCH_CHECK(xp.size(0) == B && Hp == 2 * Ho + 6 && Wp == 2 * Wo + 8 && N % 64 == 0, "conv_stem_wgrad: shape mismatch");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dy.device());
+    WinGeom g{(int)B, (int)Ho, (int)Wo, (int)N, (int)Hp, (int)(Wp / 2), 8, 32, 7, 1, 2, 1, 0, 0, 1, 0, 0};
+    TORCH_CHECK(wgrad_win_plan(g), "conv_stem_wgrad: output rows of ", Wo, " pixels do not fit the window kernel");
+    const long wsize = N * 147;
+    Tensor slab = at::empty({g.splits, wsize}, dy.options().dtype(at::kFloat));
+    launch_wgrad_win(dy.data_ptr(), xp.data_ptr(), slab.data_ptr<float>(), g, cur_stream(dy));
+    Tensor flat = g.splits == 1 ? slab.view({wsize}) : reduce_slab(slab, g.splits, wsize);
+    return flat.view({N, 7, 7, 3}).permute({0, 3, 1, 2});
 }
 
 Tensor transpose_weight(const Tensor& w) {
@@ -650,6 +739,9 @@ void bind_ops(pybind11::module& m) {
     m.def("conv2d_dgrad", &conv2d_dgrad, pybind11::arg("dy"), pybind11::arg("wt"), pybind11::arg("x_shape"), pybind11::arg("kh"),
           pybind11::arg("kw"), pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("addend") = pybind11::none());
     m.def("conv2d_wgrad", &conv2d_wgrad);
+    m.def("conv_stem_fwd", &conv_stem_fwd);
+    m.def("stem_pack_x", &stem_pack_x);
+    m.def("conv_stem_wgrad", &conv_stem_wgrad);
     m.def("transpose_weight", &transpose_weight);
     m.def("transpose_weights", &transpose_weights, pybind11::arg("weights"), pybind11::arg("outs") = pybind11::none());
     m.def("bn_stats", &bn_stats);

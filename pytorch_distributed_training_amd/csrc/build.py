@@ -24,7 +24,7 @@ ARCH = "gfx950"
 
 HIP_SOURCES = [
     "kernels/elementwise.hip", "kernels/softmax_ce.hip", "kernels/bn.hip", "kernels/pool.hip",
-    "kernels/conv_igemm.hip", "kernels/conv_wgrad.hip", "kernels/conv_stem.hip",
+    "kernels/conv_igemm.hip", "kernels/conv_wgrad.hip", "kernels/conv_wgrad_win.hip", "kernels/conv_stem.hip",
 ]
 CPP_SOURCES = ["binding/ops.cpp", "binding/module.cpp", "comm/rccl_comm.cpp", "reducer/reducer.cpp"]
 

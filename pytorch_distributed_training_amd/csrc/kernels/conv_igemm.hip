@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
         wrow[p] = (n < g.N) ? (uint32_t)n * (uint32_t)g.wtaps : 0xffffffffu;
     }
 
+    const int pix_elems = g.pix_elems ? g.pix_elems : g.C;  // memory elements per input pixel
     bf16x8 ra[PA], rb[PB];
     auto gload = [&](int t, int c0) {
         const int dh = g.dh[t], dw = g.dw[t], ws = g.wslot[t];
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
         for (int p = 0; p < PA; ++p) {
             const int hi = rih[p] + dh, wi = riw[p] + dw;
             const bool ok = (unsigned)hi < (unsigned)g.Hin && (unsigned)wi < (unsigned)g.Win;
-            const uint32_t off = (uint32_t)(((rowpix[p] + hi * g.Win + wi) * g.C + c0 + chunk * 8) * 2);
+            const uint32_t off = (uint32_t)(((rowpix[p] + hi * g.Win + wi) * pix_elems + c0 + chunk * 8) * 2);
             ra[p] = buffer_load_bf16x8(rx, ok ? off : kOOB);
         }
 #pragma unroll
@@ -267,7 +268,7 @@ void launch_cfg(const void* x, const void* w, void* y, const ConvGeom& g, float*
     size_t lds = (size_t)2 * (BM + BN) * BK * 2;                      // double-buffered operand tiles
     const size_t epi = (size_t)BM * BN * 2 + (size_t)WM * BN * 2 * 4;  // staged output tile + stats scratch
     if (lds < epi) lds = epi;
-    const uint32_t xb = (uint32_t)((long)g.B * g.Hin * g.Win * g.C * 2);
+    const uint32_t xb = (uint32_t)((long)g.B * g.Hin * g.Win * (g.pix_elems ? g.pix_elems : g.C) * 2);
     const uint32_t wb = (uint32_t)((long)g.N * g.wtaps * g.C * 2);
     static bool attr_set = false;
     if (!attr_set) {
@@ -298,6 +299,11 @@ int conv_igemm_m_tiles(const ConvGeom& g, int* bm_out) {
 void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab,
                        hipStream_t s) {
     const bool n128 = g.N % 128 == 0;
+    if (g.C % 64 != 0) {  // 32-channel K rows (the packed stem): only the BK = 32 tiles apply
+        if (n128) launch_cfg<128, 128, 2, 2, 32, 3>(x, w, y, g, stats_slab, s);
+        else launch_cfg<128, 64, 4, 1, 32, 3>(x, w, y, g, stats_slab, s);
+        return;
+    }
     switch (igemm_cfg_override()) {  // experiment knob; 0 = tuned default.  All configs use BM = 128.
         case 5:  // BK=64 everywhere (the round-1 baseline)
             if (n128) launch_cfg<128, 128, 2, 2, 64, 2>(x, w, y, g, stats_slab, s);

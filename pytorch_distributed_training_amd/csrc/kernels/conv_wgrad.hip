@@ -25,24 +25,6 @@ namespace {
 
 constexpr int KM = 64;  // pixels (reduction rows) per K-step
 
-struct FastDiv {
-    uint32_t mlo, shift, d;
-};
-inline FastDiv make_fastdiv(uint32_t d) {
-    FastDiv f;
-    f.d = d;
-    uint32_t L = 0;
-    while ((1u << L) < d) ++L;
-    const unsigned __int128 one = 1;
-    const unsigned __int128 magic = ((one << (32 + L)) + d - 1) / d;  // ceil(2^(32+L) / d), in [2^32, 2^33)
-    f.mlo = (uint32_t)(magic - (one << 32));
-    f.shift = L;
-    return f;
-}
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {  // exact for n < 2^31
-    return (n + __umulhi(n, f.mlo)) >> f.shift;
-}
-
 template <int RB>
 __device__ __forceinline__ int swz_off(int row, int ch) {
     if constexpr (RB == 256) {

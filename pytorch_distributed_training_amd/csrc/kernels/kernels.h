@@ -99,6 +99,9 @@ struct ConvGeom {
     // optional bf16 tensor with the output's shape that is added in the epilogue (fuses the residual
     // branch's gradient into the data-gradient kernel instead of a separate elementwise add)
     const void* addend;
+    // elements per input pixel in memory; 0 = C (dense NHWC).  The packed stem runs with C = 32 (one filter
+    // row: 8 kw slots x 4 channels, contiguous in memory) over pixels of 4 elements.
+    int pix_elems;
 };
 // y = conv(x, w); when stats_slab != nullptr also writes per-(m-tile) partial [sum, sum_sq] rows
 // stats_slab[m_tile][2][N] computed from the bf16-rounded outputs.
@@ -115,5 +118,27 @@ struct WgradGeom {
 int conv_wgrad_splits(const WgradGeom& g);
 // slab[split][N][KH*KW][C] fp32 partials (to be summed by launch_reduce_slab)
 void launch_conv_wgrad(const void* dy, const void* x, float* slab, const WgradGeom& g, hipStream_t s);
+
+
+// all-taps-per-workgroup weight gradient (conv_wgrad_win.hip): mode 0 = 3x3-style convs with C, N % 64 == 0;
+// mode 1 = the packed 3-channel stem (source pixel = 2 image pixels x 4 channels, tap = filter row)
+struct WinGeom {
+    int B, Ho, Wo, N;     // dy [B,Ho,Wo,N]
+    int Hs, Ws, xpix;     // x source [B,Hs,Ws,xpix]
+    int C;                // output columns per tap (conv: Cin; stem: 32)
+    int KH, KW;           // taps (stem: 7 x 1)
+    int sh, sw, ph, pw;   // stride / padding in source pixels
+    int mode;
+    int R, splits;        // filled by wgrad_win_plan
+};
+bool wgrad_win_plan(WinGeom& g);  // false: shape not supported by the window kernel
+// slab: fp32 [splits][N][KH*KW][C] (mode 0) or [splits][64][7][7][3] (mode 1)
+void launch_wgrad_win(const void* dy, const void* x, float* slab, const WinGeom& g, hipStream_t s);
+
+// ---- 3-channel stem (conv_stem.hip) -----------------------------------------------------------
+// x NHWC bf16 [B,H,W,3] -> xp [B][H+6][W+8][4] (image at row +3 / col +4, zeros elsewhere, channel 3 = 0)
+void launch_stem_pack_x(const void* x, void* xp, int B, int H, int W, hipStream_t s);
+// w [64][7][7][3] -> wp [64][7][8][4] (kw slot 0 and channel 3 are zero)
+void launch_stem_pack_w(const void* w, void* wp, int N, hipStream_t s);
 
 }  // namespace pdt

@@ -59,10 +59,10 @@ class _Conv2dFn(torch.autograd.Function):
                 _note_fallback("conv2d", why)
                 be = reference
                 want_stats = False  # the BN node's native one-pass bn_stats beats torch reductions over y
-        y, stats = be.conv2d_fwd(x, wk, stride, padding, want_stats)
+        y, stats, saved = be.conv2d_fwd(x, wk, stride, padding, want_stats, True)
         ctx.set_materialize_grads(False)  # no zero-filled gradient for the (non-differentiable) stats output
-        ctx.save_for_backward(x, wk)
-        ctx.cfg = (be, stride, padding, tuple(w.shape), w.dtype)
+        ctx.save_for_backward(saved, wk)  # `saved` is x, or the packed image of the native 3-channel stem
+        ctx.cfg = (be, stride, padding, tuple(w.shape), w.dtype, tuple(x.shape))
         if stats is not None:
             ctx.mark_non_differentiable(stats)
         return y, stats, (x.view_as(x) if with_skip else None)
@@ -70,13 +70,13 @@ class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dstats, dskip):
         x, wk = ctx.saved_tensors
-        be, stride, padding, w_shape, w_dtype = ctx.cfg
+        be, stride, padding, w_shape, w_dtype, x_shape = ctx.cfg
         dx = dw = None
         if dy is None:
             return dskip, None, None, None, None, None, None
         dy = _cl(dy)
         if ctx.needs_input_grad[0]:
-            dx = be.conv2d_dgrad(dy, wk, tuple(x.shape), stride, padding, None if dskip is None else _cl(dskip))
+            dx = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, None if dskip is None else _cl(dskip))
         if ctx.needs_input_grad[1]:
             dw = be.conv2d_wgrad(dy, x, w_shape, stride, padding)
             if dw.dtype != w_dtype:

@@ -27,6 +27,12 @@ def conv_unsupported_reason(x, w, stride: int, padding: int):
     if x.dtype != _BF16 or w.dtype != _BF16:
         return f"dtype {x.dtype}/{w.dtype} (native conv is bf16)"
     cout, cin, kh, kw = w.shape
+    if _is_stem(w, stride, padding):
+        if x.shape[2] % 2 or x.shape[3] % 2 or x.shape[3] // 2 > 112 or cout % 64:
+            return f"stem input {tuple(x.shape)}"
+        if x.shape[0] * (x.shape[2] + 6) * (x.shape[3] + 8) * 8 >= (1 << 31) or x.shape[0] * x.shape[2] * x.shape[3] * cout // 2 >= (1 << 31):
+            return "activation >= 2 GiB"
+        return None
     if cin % 64 or cout % 64:
         return f"channels {cin}->{cout} not multiples of 64"
     if kh * kw > 49 or stride not in (1, 2):
@@ -45,6 +51,11 @@ def bn_unsupported_reason(x):
     if x.numel() * 2 >= (1 << 31):
         return "activation >= 2 GiB"
     return None
+
+
+def _is_stem(w, stride, padding) -> bool:
+    """7x7 / 2 / pad 3 on 3 input channels: runs on the packed image of csrc/kernels/conv_stem.hip"""
+    return tuple(w.shape[1:]) == (3, 7, 7) and stride == 2 and padding == 3
 
 
 def _w_cl(w):
@@ -85,10 +96,17 @@ def _transposed(w):
     return ent[1]
 
 
-def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False):
-    _register_weight(w)
-    y, stats = _C.conv2d_fwd(x, _w_cl(w), stride, padding, want_stats)
-    return y, (stats if want_stats else None)
+def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False, return_saved: bool = False):
+    """-> (y, stats[, saved]): ``saved`` is the tensor ``conv2d_wgrad`` wants as its ``x`` (the input
+    itself, or the stem's packed image)."""
+    if _is_stem(w, stride, padding):
+        y, stats, saved = _C.conv_stem_fwd(x, _w_cl(w), want_stats)
+    else:
+        _register_weight(w)
+        y, stats = _C.conv2d_fwd(x, _w_cl(w), stride, padding, want_stats)
+        saved = x
+    stats = stats if want_stats else None
+    return (y, stats, saved) if return_saved else (y, stats)
 
 
 def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None):
@@ -100,6 +118,10 @@ def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None):
 
 
 def conv2d_wgrad(dy, x, w_shape, stride: int, padding: int):
+    if tuple(w_shape[1:]) == (3, 7, 7) and stride == 2 and padding == 3:
+        if x.shape[-1] != 4:  # the plain input: pack it (callers on the autograd path hand over the saved image)
+            x = _C.stem_pack_x(x)
+        return _C.conv_stem_wgrad(dy, x)
     return _C.conv2d_wgrad(dy, x, w_shape[2], w_shape[3], stride, padding)
 
 

@@ -14,13 +14,13 @@ import torch.nn.functional as F
 
 
 # ----------------------------------------------------------------- conv ----
-def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False):
+def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False, return_saved: bool = False):
     y = F.conv2d(x, w.to(x.dtype), None, stride, padding)
+    stats = None
     if want_stats:
         yf = y.float()
         stats = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))], 0)[None]  # partial rows [1, 2, C]
-        return y, stats
-    return y, None
+    return (y, stats, x) if return_saved else (y, stats)
 
 
 def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None):
