@@ -48,9 +48,10 @@ def main(argv=None) -> int:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam", "adamw"])
     ap.add_argument("--sync_bn", action="store_true")
-    ap.add_argument("--bucket_cap_mb", type=float, default=None)
+    ap.add_argument("--bucket_cap_mb", type=lambda v: v if v == "auto" else float(v), default=None)
     ap.add_argument("--backend", default=None)
     ap.add_argument("--reducer", default=None)
+    ap.add_argument("--graph", action="store_true", help="capture the steady-state step in one hipGraph")
     args = ap.parse_args(argv)
 
     from pytorch_distributed_training_amd import dist as pdist
@@ -70,7 +71,7 @@ def main(argv=None) -> int:
     engine = Engine(EngineConfig(
         model=args.model, num_classes=args.num_classes, dtype=args.dtype, optimizer=args.optimizer,
         lr=0.1 if args.optimizer == "sgd" else 1e-3, momentum=0.9, weight_decay=1e-4 if args.optimizer == "sgd" else 0.0,
-        sync_bn=args.sync_bn, bucket_cap_mb=args.bucket_cap_mb, reducer=args.reducer, seed=0,
+        sync_bn=args.sync_bn, bucket_cap_mb=args.bucket_cap_mb, reducer=args.reducer, seed=0, graph=args.graph,
         image_size=args.image_size))
     loader = SyntheticDeviceLoader(args.batch_size, (3, args.image_size, args.image_size), args.num_classes,
                                    device=env.device, dtype=torch.float32, ring=2, seed=env.rank)
@@ -126,6 +127,7 @@ def main(argv=None) -> int:
                 "optimizer": args.optimizer, "sync_bn": bool(args.sync_bn), "reducer": engine.net.reducer_kind,
                 "backend": env.backend, "baseline_images_per_sec": round(base, 1),
                 "library_fallbacks": dict(pF.fallback_counts), "final_loss": final_loss,
+                "hip_graph": bool(engine._graph is not None), "bucket_autotune": engine.net.bucket_autotune,
             },
         }
         print(json.dumps(out), flush=True)

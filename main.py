@@ -61,7 +61,8 @@ def get_parser() -> argparse.ArgumentParser:
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="GPU compute dtype")
     p.add_argument("--sync_bn", dest="sync_bn", action="store_true", default=True)
     p.add_argument("--no_sync_bn", dest="sync_bn", action="store_false")
-    p.add_argument("--bucket_cap_mb", default=None, type=float)
+    p.add_argument("--bucket_cap_mb", default=None, type=lambda v: v if v == "auto" else float(v),
+                   help="gradient bucket size in MiB, or 'auto' to time all-reduces on this job's links and pick one")
     p.add_argument("--backend", default=None, choices=["rccl", "nccl", "gloo"])
     p.add_argument("--steps", default=None, type=int, help="stop after this many iterations (benchmarks)")
     p.add_argument("--checkpoint", default=None, type=str, help="save a checkpoint here at the end of each epoch")
@@ -69,6 +70,8 @@ def get_parser() -> argparse.ArgumentParser:
     p.add_argument("--resume", default=None, type=str)
     p.add_argument("--profile", default="torch", choices=["none", "torch", "roctx"])
     p.add_argument("--seed", default=None, type=int)
+    p.add_argument("--graph", action="store_true",
+                   help="capture forward+backward+optimizer of the steady-state step in one hipGraph")
     p.add_argument("--eval", action="store_true", help="run the top-1 evaluation after training (main.py:119-130)")
     p.add_argument("--summary_json", default=None, type=str)
     p.add_argument("--log_dir", default=".", type=str)
@@ -99,7 +102,7 @@ def main(argv=None) -> int:
         engine = Engine(EngineConfig(
             model=args.model, num_classes=args.num_classes, dtype=args.dtype, optimizer=args.optimizer, lr=args.lr,
             momentum=args.momentum, weight_decay=args.weight_decay, sync_bn=args.sync_bn,
-            bucket_cap_mb=args.bucket_cap_mb, seed=args.seed,
+            bucket_cap_mb=args.bucket_cap_mb, seed=args.seed, graph=args.graph,
             image_size=trainset.sample_shape[1]))
         start_epoch, global_step = 0, 0
         if args.resume:

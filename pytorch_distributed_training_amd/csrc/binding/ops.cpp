@@ -700,8 +700,15 @@ void fill_cols(const std::vector<Tensor>& ps, const std::vector<Tensor>& gs, con
 
 void multi_adam(std::vector<Tensor> ps, std::vector<Tensor> gs, std::vector<Tensor> ms, std::vector<Tensor> vs,
                 std::vector<c10::optional<Tensor>> lps, double lr, double beta1, double beta2, double eps,
-                double weight_decay, int64_t step, bool adamw, double grad_scale) {
+                double weight_decay, int64_t step, bool adamw, double grad_scale,
+                const c10::optional<Tensor>& step_dev) {
     if (ps.empty()) return;
+    const float* step_ptr = nullptr;
+    if (step_dev.has_value() && step_dev->defined()) {
+        TORCH_CHECK(step_dev->is_cuda() && step_dev->scalar_type() == at::kFloat && step_dev->numel() == 1,
+                    "step_dev: expected a 1-element fp32 GPU tensor");
+        step_ptr = step_dev->data_ptr<float>();
+    }
     std::vector<std::vector<const Tensor*>> cols;
     std::vector<int64_t> numels;
     fill_cols(ps, gs, &ms, &vs, lps, cols, numels);
@@ -710,7 +717,7 @@ void multi_adam(std::vector<Tensor> ps, std::vector<Tensor> gs, std::vector<Tens
     const double bc1 = 1.0 - std::pow(beta1, (double)step);
     const double bc2 = 1.0 - std::pow(beta2, (double)step);
     launch_multi_adam(t.dev.data_ptr<int64_t>(), t.ntensors, t.nchunks, (float)lr, (float)beta1, (float)beta2,
-                      (float)eps, (float)weight_decay, (float)bc1, (float)std::sqrt(bc2), adamw ? 1 : 0,
+                      (float)eps, (float)weight_decay, (float)bc1, (float)std::sqrt(bc2), step_ptr, adamw ? 1 : 0,
                       (float)grad_scale, dtype_code(gs[0].scalar_type()), cur_stream(ps[0]));
 }
 
@@ -757,7 +764,10 @@ void bind_ops(pybind11::module& m) {
     m.def("softmax_ce", &softmax_ce);
     m.def("to_nhwc_bf16", &to_nhwc_bf16);
     m.def("multi_flatten", &multi_flatten);
-    m.def("multi_adam", &multi_adam);
+    m.def("multi_adam", &multi_adam, pybind11::arg("params"), pybind11::arg("grads"), pybind11::arg("exp_avg"),
+          pybind11::arg("exp_avg_sq"), pybind11::arg("lowp"), pybind11::arg("lr"), pybind11::arg("beta1"),
+          pybind11::arg("beta2"), pybind11::arg("eps"), pybind11::arg("weight_decay"), pybind11::arg("step"),
+          pybind11::arg("adamw"), pybind11::arg("grad_scale"), pybind11::arg("step_dev") = pybind11::none());
     m.def("multi_sgd", &multi_sgd);
 }
 

@@ -122,7 +122,13 @@ __global__ __launch_bounds__(256) void k_flatten_args(const FlatArgs a, float sc
 template <typename G>
 __global__ __launch_bounds__(256) void k_multi_adam(const int64_t* __restrict__ table, int ntensors, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1,
-                                                    float bc2_sqrt, int adamw, float gscale) {
+                                                    float bc2_sqrt, const float* __restrict__ step_dev, int adamw,
+                                                    float gscale) {
+    if (step_dev != nullptr) {  // graph-capturable form: the step count lives in device memory
+        const double st = (double)*step_dev;
+        bc1 = (float)(1.0 - pow((double)beta1, st));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, st));
+    }
     const Row* r;
     long base;
     locate(table, ntensors, blockIdx.x, r, base);
@@ -335,16 +341,16 @@ void launch_flatten_args(const FlatArgs& a, float scale, int src_dtype, int dst_
 }
 
 void launch_multi_adam(const int64_t* table, int ntensors, int nchunks, float lr, float beta1, float beta2,
-                       float eps, float weight_decay, float bias_corr1, float bias_corr2_sqrt, int adamw,
-                       float grad_scale, int grad_dtype, hipStream_t s) {
+                       float eps, float weight_decay, float bias_corr1, float bias_corr2_sqrt,
+                       const float* step_dev, int adamw, float grad_scale, int grad_dtype, hipStream_t s) {
     if (nchunks <= 0) return;
     dim3 grid(nchunks), block(256);
     if (grad_dtype == kF32)
         hipLaunchKernelGGL((k_multi_adam<float>), grid, block, 0, s, table, ntensors, lr, beta1, beta2, eps,
-                           weight_decay, bias_corr1, bias_corr2_sqrt, adamw, grad_scale);
+                           weight_decay, bias_corr1, bias_corr2_sqrt, step_dev, adamw, grad_scale);
     else
         hipLaunchKernelGGL((k_multi_adam<bf16>), grid, block, 0, s, table, ntensors, lr, beta1, beta2, eps,
-                           weight_decay, bias_corr1, bias_corr2_sqrt, adamw, grad_scale);
+                           weight_decay, bias_corr1, bias_corr2_sqrt, step_dev, adamw, grad_scale);
 }
 
 void launch_multi_sgd(const int64_t* table, int ntensors, int nchunks, float lr, float momentum, float dampening,

@@ -25,8 +25,9 @@ struct FlatArgs {
 };
 void launch_flatten_args(const FlatArgs& a, float scale, int src_dtype, int dst_dtype, hipStream_t s);
 void launch_multi_adam(const int64_t* table, int ntensors, int nchunks, float lr, float beta1, float beta2,
-                       float eps, float weight_decay, float bias_corr1, float bias_corr2_sqrt, int adamw,
-                       float grad_scale, int grad_dtype, hipStream_t s);
+                       float eps, float weight_decay, float bias_corr1, float bias_corr2_sqrt,
+                       const float* step_dev /* non-null: bias corrections from this device step count */,
+                       int adamw, float grad_scale, int grad_dtype, hipStream_t s);
 void launch_multi_sgd(const int64_t* table, int ntensors, int nchunks, float lr, float momentum, float dampening,
                       float weight_decay, int nesterov, int first, float grad_scale, int grad_dtype,
                       hipStream_t s);

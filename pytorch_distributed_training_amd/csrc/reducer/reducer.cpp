@@ -64,6 +64,11 @@ Reducer::Reducer(std::vector<at::Tensor> params, std::vector<std::string> names,
     for (int64_t i = (int64_t)params_.size() - 1; i >= 0; --i) order.push_back(i);
     build(order);
 
+    install_hooks();
+}
+
+void Reducer::install_hooks() {
+    remove_hooks();
     // hooks on the AccumulateGrad nodes: fire after .grad has been written
     for (size_t i = 0; i < params_.size(); ++i) {
         if (!params_[i].requires_grad()) continue;
@@ -191,7 +196,7 @@ void Reducer::launch(Bucket& b) {
     }
     if (!srcs.empty()) multi_flatten_tensors(srcs, dsts, scale);  // one launch: copy + 1/W (+ cast)  (N2)
 
-    if (world_ > 1) {
+    if (rccl_ || pg_) {  // (a size-1 communicator is legal: the GPU tests use it to run this exact path)
         if (rccl_ && is_cuda_) {
             hipStream_t compute = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(b.flat.device().index()).stream();
             rccl_->fence_from(compute);           // comm stream waits for the flatten
@@ -216,7 +221,7 @@ void Reducer::finalize() {
         launch(buckets_[next_bucket_]);
         ++next_bucket_;
     }
-    if (world_ > 1) {
+    if (rccl_ || pg_) {
         if (rccl_ && is_cuda_) {
             hipStream_t compute = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(params_[0].device().index()).stream();
             for (auto& b : buckets_) PDT_HIP(hipStreamWaitEvent(compute, b.done, 0));

@@ -54,6 +54,9 @@ class Reducer {
     std::vector<int64_t> bucket_numels() const;
     std::vector<at::Tensor> bucket_tensors() const;
     void remove_hooks();
+    // (re)create the AccumulateGrad nodes and their post hooks.  A node is bound to the stream that is current
+    // when it is created, so before a hipGraph capture this is called under the capture stream.
+    void install_hooks();
 
    private:
     struct Bucket {

@@ -40,6 +40,10 @@ class EngineConfig:
     reducer: str | None = None
     seed: int | None = None
     image_size: int | None = None
+    # capture forward + backward + optimizer of the steady-state step in one hipGraph (launch-bound shapes:
+    # the CIFAR-shaped reference config issues ~550 kernels of a few microseconds each per step)
+    graph: bool = False
+    graph_warmup: int = 3
 
 
 def compute_dtype(cfg: EngineConfig, device: torch.device) -> torch.dtype:
@@ -73,6 +77,13 @@ class Engine:
             bucket_cap_mb=cfg.bucket_cap_mb, broadcast_buffers=cfg.broadcast_buffers,
             compute_dtype=self.dtype, reducer=cfg.reducer)
         self.net.train()
+        self._graph = None          # (CUDAGraph, static_imgs, static_labels, static_loss)
+        self._graph_key = None
+        self._eager_steps = 0
+        self._graph_failed = None
+        self._capture_stream = None
+        if cfg.graph and self.device.type == "cuda" and hasattr(self.optimizer, "set_capturable"):
+            self.optimizer.set_capturable(True)
 
     # ------------------------------------------------------------------ data
     def prepare_input(self, imgs: torch.Tensor) -> torch.Tensor:
@@ -90,6 +101,54 @@ class Engine:
     def train_step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         """One iteration in the reference's order; returns the local loss tensor
         (fp32 scalar on the device, not synchronised with the host)."""
+        if self.cfg.graph and self.device.type == "cuda" and self._graph_failed is None:
+            return self._graph_step(imgs, labels)
+        return self._eager_step(imgs, labels)
+
+    def _graph_step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """Replay the captured step when the batch has the captured shape; run eagerly otherwise (warm-up
+        steps: reducer rebuild, lazy optimizer state, kernel attributes; and the short last batch of an epoch)."""
+        key = (tuple(imgs.shape), imgs.dtype, tuple(labels.shape), labels.dtype)
+        if self._graph is not None and key == self._graph_key:
+            g, s_imgs, s_labels, s_loss = self._graph
+            s_imgs.copy_(imgs, non_blocking=True)
+            s_labels.copy_(labels, non_blocking=True)
+            g.replay()
+            return s_loss
+        if self._graph is None and self._eager_steps >= self.cfg.graph_warmup and self.net._require_sync:
+            try:
+                self._capture(imgs, labels, key)
+                return self._graph[3]
+            except Exception as e:  # leave the job running on the eager path and say why
+                self._graph_failed = repr(e)
+                self._graph = None
+                torch.cuda.synchronize(self.device)
+                if self.rank == 0:
+                    print(f"[pdt] hipGraph capture failed, continuing eagerly: {self._graph_failed}", flush=True)
+        return self._eager_step(imgs, labels)
+
+    def _capture(self, imgs, labels, key) -> None:
+        s_imgs = imgs.to(self.device, copy=True)
+        s_labels = labels.to(self.device, copy=True)
+        torch.cuda.synchronize(self.device)
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(self._capture_stream):
+            # autograd runs an AccumulateGrad node on the stream it was created on: the reducer keeps those
+            # nodes alive, so re-create them on the capture stream (and free the ones the warm-up made)
+            for p in self.net.parameters():
+                p.grad = None
+            if hasattr(self.net.reducer, "rehook"):
+                self.net.reducer.rehook()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self._capture_stream):
+            s_loss = self._eager_step(s_imgs, s_labels)
+        self._graph, self._graph_key = (g, s_imgs, s_labels, s_loss), key
+        # the capture pass enqueued nothing: run the step it recorded for this batch
+        g.replay()
+
+    def _eager_step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        self._eager_steps += 1
         with profiling.range_("h2d+cast"):
             x = self.prepare_input(imgs)
             labels = labels.to(self.device, non_blocking=True)

@@ -222,7 +222,10 @@ def nchw_to_nhwc_lowp(x, dtype=_BF16, scale: float = 1.0):
 
 
 # --------------------------------------------------------------- optimizers
-def multi_adam(params, grads, ms, vs, lps, lr, beta1, beta2, eps, weight_decay, step, adamw, grad_scale=1.0):
+def multi_adam(params, grads, ms, vs, lps, lr, beta1, beta2, eps, weight_decay, step, adamw, grad_scale=1.0,
+               step_dev=None):
+    """``step_dev`` (fp32 device scalar holding the step count): the bias corrections are computed in the kernel
+    from it, so a captured graph replays correctly; ``step`` is then only used by the fallback path."""
     ok = all(_aligned(t) for t in (*params, *grads, *ms, *vs)) and all(lp is None or _aligned(lp) for lp in lps) \
         and all(p.dtype == torch.float32 for p in params) and len({g.dtype for g in grads}) == 1
     if not ok:
@@ -231,7 +234,7 @@ def multi_adam(params, grads, ms, vs, lps, lr, beta1, beta2, eps, weight_decay, 
         bump_weights_epoch()
         return
     _C.multi_adam(list(params), list(grads), list(ms), list(vs), list(lps), lr, beta1, beta2, eps, weight_decay,
-                  int(step), bool(adamw), grad_scale)
+                  int(step), bool(adamw), grad_scale, step_dev)
     bump_weights_epoch()
 
 

@@ -67,6 +67,48 @@ class _FusedBase(Optimizer):
         for p in missing:
             self.state[p].setdefault("step", torch.tensor(0.0))
 
+    # -- step counters: one Python int per group on the hot path; the per-parameter ``state[p]["step"]``
+    #    tensors of the stock layout are only materialised for state_dict() ---------------------------------
+    def _group_step(self, gi: int, params) -> int | None:
+        """Current step count of group ``gi`` (None if its parameters disagree, e.g. after a partial load)."""
+        steps = self.__dict__.setdefault("_fused_steps", {})
+        if gi not in steps:
+            seen = {int(float(self.state[p]["step"])) for p in params if "step" in self.state[p]}
+            if len(seen) > 1:
+                return None
+            steps[gi] = seen.pop() if seen else 0
+        return steps[gi]
+
+    def _sync_step_tensors(self) -> None:
+        steps = self.__dict__.get("_fused_steps", {})
+        devs = self.__dict__.get("_step_dev", {})
+        for gi, group in enumerate(self.param_groups):
+            if gi in devs and gi in steps:  # graph replays advance only the device counter
+                steps[gi] = int(round(float(devs[gi].item())))
+            if gi not in steps:
+                continue
+            for p in group["params"]:
+                if p in self.state and "step" in self.state[p]:
+                    self.state[p]["step"] = torch.tensor(float(steps[gi]))
+
+    def state_dict(self):
+        self._sync_step_tensors()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.__dict__.pop("_fused_steps", None)  # re-derived from the loaded per-parameter steps
+        for gi, t in self.__dict__.get("_step_dev", {}).items():
+            params = [p for p in self.param_groups[gi]["params"] if p in self.state]
+            st = self._group_step(gi, params)
+            if st is not None:
+                t.fill_(float(st))
+
+    def set_capturable(self, on: bool = True) -> None:
+        """Keep the step count in device memory so a captured hipGraph replays with the right bias
+        correction (the host only advances it when Python actually runs ``step()``)."""
+        self.__dict__["_capturable"] = bool(on)
+
     def _move_loaded_state(self, params):
         # after load_state_dict the state tensors may sit on another device / layout
         for p in params:
@@ -93,28 +135,36 @@ class Adam(_FusedBase):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             params = self._collect(group)
             if not params:
                 continue
             self._lazy_state(group, params)
             self._move_loaded_state(params)
             b1, b2 = group["betas"]
-            steps = set()
-            for p in params:
-                st = self.state[p]
-                st["step"] += 1
-                steps.add(int(st["step"].item()) if st["step"].device.type == "cpu" else None)
+            step = self._group_step(gi, params)
             grads = [_grad_like(p) for p in params]
             ms = [self.state[p]["exp_avg"] for p in params]
             vs = [self.state[p]["exp_avg_sq"] for p in params]
             lps = [getattr(p, "_lp", None) for p in params]
             be = backend_for(params[0])
-            if be is not reference and len(steps) == 1 and None not in steps:
+            if be is not reference and step is not None:
+                step += 1
+                self._fused_steps[gi] = step
+                step_dev = None
+                if self.__dict__.get("_capturable", False):
+                    devs = self.__dict__.setdefault("_step_dev", {})
+                    if gi not in devs:
+                        devs[gi] = torch.full((1,), float(step - 1), dtype=torch.float32, device=params[0].device)
+                    step_dev = devs[gi]
+                    step_dev.add_(1.0)
                 be.multi_adam(params, grads, ms, vs, lps, group["lr"], b1, b2, group["eps"],
-                              group["weight_decay"], steps.pop(), self._adamw, self.grad_scale)
+                              group["weight_decay"], step, self._adamw, self.grad_scale, step_dev)
             else:
+                self._sync_step_tensors()
+                self.__dict__.get("_fused_steps", {}).pop(gi, None)
                 for p, g, m, v, lp in zip(params, grads, ms, vs, lps):
+                    self.state[p]["step"] += 1
                     reference.adam_step(p, g, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"],
                                         float(self.state[p]["step"]), self._adamw, self.grad_scale, lp)
         return loss
@@ -146,15 +196,19 @@ class SGD(_FusedBase):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             params = self._collect(group)
             if not params:
                 continue
             first = [not all(k in self.state[p] for k in self._state_keys) for p in params]
             self._lazy_state(group, params)
             self._move_loaded_state(params)
-            for p in params:
-                self.state[p]["step"] += 1
+            step = self._group_step(gi, params)
+            if step is not None:
+                self._fused_steps[gi] = step + 1
+            else:
+                for p in params:
+                    self.state[p]["step"] += 1
             grads = [_grad_like(p) for p in params]
             bufs = [self.state[p]["momentum_buffer"] for p in params]
             lps = [getattr(p, "_lp", None) for p in params]

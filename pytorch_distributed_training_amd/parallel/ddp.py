@@ -46,7 +46,7 @@ def _param_signature_hash(module: tnn.Module) -> int:
 
 class DistributedDataParallel(tnn.Module):
     def __init__(self, module: tnn.Module, device_ids=None, output_device=None, process_group=None,
-                 bucket_cap_mb: float | None = None, first_bucket_mb: float | None = None,
+                 bucket_cap_mb: float | str | None = None, first_bucket_mb: float | None = None,
                  broadcast_buffers: bool | str = "auto", gradient_as_bucket_view: bool = True,
                  grad_dtype: torch.dtype | None = None, compute_dtype: torch.dtype | None = None,
                  reducer: str | None = None, find_unused_parameters: bool = False, check_replicas: bool = False):
@@ -92,6 +92,12 @@ class DistributedDataParallel(tnn.Module):
             broadcast_buffers = any(not isinstance(m, (SyncBatchNorm, tnn.SyncBatchNorm)) for m in bns)
         self.broadcast_buffers = bool(broadcast_buffers) and self.world_size > 1
 
+        self.bucket_autotune = None
+        if isinstance(bucket_cap_mb, str):
+            if bucket_cap_mb.lower() != "auto":
+                bucket_cap_mb = float(bucket_cap_mb)
+            else:
+                bucket_cap_mb = self._autotune_bucket_cap(grad_dtype or torch.float32)
         cap = int((bucket_cap_mb if bucket_cap_mb is not None else
                    float(os.environ.get("PDT_BUCKET_CAP_MB", DEFAULT_BUCKET_CAP_MB))) * (1 << 20))
         first = int((first_bucket_mb if first_bucket_mb is not None else
@@ -112,6 +118,29 @@ class DistributedDataParallel(tnn.Module):
                                      gradient_as_bucket_view, names)
         self.reducer_kind = kind
         self._require_sync = True
+
+    def _autotune_bucket_cap(self, dtype) -> float:
+        """``bucket_cap_mb="auto"``: time the all-reduce of a few bucket sizes on THIS job's links (xGMI ring
+        steps are per-link bound, a PCIe / multi-node fabric behaves differently) and keep the smallest size
+        within 10 % of the best bus bandwidth: smaller buckets start the overlap earlier in backward.  Rank 0's
+        pick is broadcast so every rank plans identical buckets."""
+        from .buckets import DEFAULT_BUCKET_CAP_MB, autotune_bucket_cap
+
+        if self.world_size == 1:
+            return float(DEFAULT_BUCKET_CAP_MB)
+
+        def timed(t):
+            self.comm.all_reduce(t)
+            if t.is_cuda:
+                torch.cuda.synchronize(t.device)
+
+        _, res = autotune_bucket_cap(timed, self.device, dtype, candidates_mb=(4, 8, 16, 32, 64))
+        best_bw = max(mb / s for mb, s in res.items())
+        pick = min(mb for mb, s in res.items() if mb / s >= 0.9 * best_bw)
+        t = torch.tensor([float(pick)], dtype=torch.float32, device=self.device)
+        self.comm.broadcast(t, 0)
+        self.bucket_autotune = {"picked_mb": float(t.item()), "seconds_per_allreduce": {str(k): v for k, v in res.items()}}
+        return float(t.item())
 
     # ------------------------------------------------------------------ API
     def forward(self, *inputs, **kwargs):

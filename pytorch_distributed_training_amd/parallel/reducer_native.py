@@ -8,6 +8,7 @@ hash-check + rebuild between iteration 1 and 2.
 from __future__ import annotations
 
 import itertools
+import os
 
 import torch
 import torch.distributed as tdist
@@ -26,11 +27,16 @@ def make_rccl_comm(group=None, high_priority: bool = True):
     every rank then joins with ``ncclCommInitRank``.
     """
     C = require_native()
-    if not (tdist.is_available() and tdist.is_initialized()) or tdist.get_world_size(group) == 1:
-        return None
     key = (id(group), high_priority)
     if key in _shared_comm:
         return _shared_comm[key]
+    if not (tdist.is_available() and tdist.is_initialized()) or tdist.get_world_size(group) == 1:
+        if os.environ.get("PDT_FORCE_COMM", "0") != "1":
+            return None
+        # size-1 communicator: lets one GPU run the real flatten -> fence -> ncclAllReduce -> event path
+        comm = C.RcclComm(0, 1, C.RcclComm.make_unique_id(), torch.cuda.current_device(), high_priority)
+        _shared_comm[key] = comm
+        return comm
     rank, world = tdist.get_rank(group), tdist.get_world_size(group)
     store = tdist.distributed_c10d._get_default_store()
     name = f"pdt/rccl_uid/{next(_comm_counter)}"
@@ -53,11 +59,10 @@ class NativeReducer:
         names = list(names) if names is not None else [f"param{i}" for i in range(len(self.params))]
         self.rccl = None
         pg = None
-        if self.world > 1:
-            if self.device.type == "cuda":
-                self.rccl = make_rccl_comm(process_group, high_priority=True)
-            else:
-                pg = process_group if process_group is not None else tdist.distributed_c10d._get_default_group()
+        if self.device.type == "cuda":
+            self.rccl = make_rccl_comm(process_group, high_priority=True)  # None at world 1 unless PDT_FORCE_COMM=1
+        elif self.world > 1:
+            pg = process_group if process_group is not None else tdist.distributed_c10d._get_default_group()
         self._r = C.Reducer(self.params, names, self.rccl, pg, self.world, int(bucket_cap_bytes),
                             int(first_bucket_bytes), grad_dtype, bool(gradient_as_bucket_view))
         self._require_sync = True
@@ -106,3 +111,8 @@ class NativeReducer:
 
     def remove_hooks(self) -> None:
         self._r.remove_hooks()
+
+    def rehook(self) -> None:
+        """Recreate the AccumulateGrad nodes under the CURRENT stream (they remember the stream they were
+        created on; a hipGraph capture must not pull the default stream in through them)."""
+        self._r.install_hooks()

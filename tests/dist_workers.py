@@ -104,6 +104,14 @@ def ddp_grads(rank, world, reducer="py", sync_bn=True, bucket_cap_mb=None, steps
     return out
 
 
+def bucket_autotune(rank, world):
+    """bucket_cap_mb="auto": every rank ends up with rank 0's pick and identical bucket plans."""
+    from pytorch_distributed_training_amd.parallel import DistributedDataParallel
+
+    ddp = DistributedDataParallel(_toy(seed=rank), reducer="py", bucket_cap_mb="auto")
+    return {"tune": ddp.bucket_autotune, "buckets": [list(b.param_indices) for b in ddp.reducer.bucket_specs()]}
+
+
 def _bucket_tensors(ddp):
     r = ddp.reducer
     return r.bucket_tensors() if hasattr(r, "bucket_tensors") else [b.flat for b in r.buckets]

@@ -189,3 +189,11 @@ def test_main_py_two_ranks_gloo(tmp_path, free_port, repo_root):
                         text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr[-3000:]
     assert "Epoch: 1 step: 0" in r2.stdout and "Epoch: 0 step: 0" not in r2.stdout
+
+
+def test_bucket_cap_autotune_agrees_across_ranks(free_port, tmp_path):
+    res = spawn("bucket_autotune", 2, free_port, tmp_path)
+    picks = [r["tune"]["picked_mb"] for r in res]
+    assert picks[0] == picks[1] and picks[0] in (4.0, 8.0, 16.0, 32.0, 64.0)
+    assert set(res[0]["tune"]["seconds_per_allreduce"]) == {"4", "8", "16", "32", "64"}
+    assert res[0]["buckets"] == res[1]["buckets"]

@@ -193,6 +193,57 @@ def test_bf16_native_matches_oracles(model):
     print(f"{model}: worst gradient cosine vs fp32: library-bf16 {worst_b:.4f}, native {worst_c:.4f}")
 
 
+def test_reducer_runs_the_rccl_path_with_a_size1_communicator(tmp_path):
+    """The multi-GPU hot path (multi-tensor flatten -> fence -> ncclAllReduce on the communicator's stream ->
+    per-bucket event -> optimizer) on one GPU: PDT_FORCE_COMM=1 gives the C++ reducer a size-1 communicator, and
+    the run must reproduce the losses of the plain W=1 run bit for bit."""
+    code = (
+        "import os, sys, json, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from pytorch_distributed_training_amd import dist as pdist\n"
+        "from pytorch_distributed_training_amd.engine import Engine, EngineConfig\n"
+        "pdist.init_process_group(backend='rccl', local_rank=0)\n"
+        "eng = Engine(EngineConfig(model='resnet18', num_classes=10, dtype='bf16', optimizer='sgd', lr=0.05, seed=0))\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "x = torch.rand(32, 3, 64, 64, generator=g).cuda(); y = torch.randint(0, 10, (32,), generator=g).cuda()\n"
+        "losses = [float(eng.train_step(x, y)) for _ in range(6)]\n"
+        "print(json.dumps({'losses': losses, 'rccl': eng.net.reducer.rccl is not None, 'kind': eng.net.reducer_kind}))\n"
+    ) % ROOT
+    outs = []
+    for force in ("0", "1"):
+        env = dict(os.environ, PDT_FORCE_COMM=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", RANK="0",
+                   WORLD_SIZE="1", LOCAL_RANK="0")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=tmp_path)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["kind"] == outs[1]["kind"] == "native"
+    assert not outs[0]["rccl"] and outs[1]["rccl"]
+    assert outs[0]["losses"] == outs[1]["losses"], outs
+    assert outs[1]["losses"][-1] < outs[1]["losses"][0]
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_hip_graph_step_matches_eager(opt):
+    """Engine(graph=True) captures forward+backward+optimizer after 3 eager steps; replays must produce the same
+    losses as the eager engine (Adam's bias correction comes from the device-side step counter)."""
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.rand(32, 3, 32, 32, generator=g).cuda() for _ in range(2)] * 4  # two alternating batches
+    ys = [torch.randint(0, 10, (32,), generator=g).cuda() for _ in range(2)] * 4
+    runs = []
+    for graph in (False, True):
+        eng = _engine(model="resnet18", num_classes=10, optimizer=opt, lr=0.01 if opt == "sgd" else 1e-3, graph=graph)
+        eng.optimizer.set_capturable(True)  # same (device-side) bias-correction arithmetic in both runs
+        losses = [float(eng.train_step(x, y)) for x, y in zip(xs, ys)]
+        runs.append(losses)
+        if graph:
+            assert eng._graph is not None, eng._graph_failed
+            if opt == "adam":  # the device-side counter advanced on every replay and is what state_dict() reports
+                sd = eng.optimizer.state_dict()
+                assert all(int(v["step"]) == 8 for v in sd["state"].values())
+    assert runs[0] == pytest.approx(runs[1], rel=2e-3), runs
+    assert runs[1][-2] < runs[1][0] and runs[1][-1] < runs[1][1], runs
+
+
 def test_main_py_single_gpu_through_launcher(tmp_path):
     """SURVEY §7.3 exit criteria: loss decreases, byte-exact log header, profiler trace, strict checkpoint."""
     env = dict(os.environ, PYTHONPATH=ROOT)
