@@ -248,6 +248,33 @@ def check_bn(B, C, H, W, time_it):
     run_case(f"bn_bwd {tag}", bwd)
 
 
+def check_layernorm(M, D, time_it):
+    tag = f"M{M} D{D}"
+    x = (torch.randn(M, D, device=DEV) * 2 + 0.3).to(torch.bfloat16)
+    dy = torch.randn(M, D, device=DEV).to(torch.bfloat16)
+    gamma = torch.rand(D, device=DEV) + 0.5
+    beta = torch.randn(D, device=DEV) * 0.1
+
+    def run():
+        y, mean, rstd = native.layernorm_fwd(x, gamma, beta, 1e-6)
+        yr, mr, rr = reference.layernorm_fwd(x, gamma, beta, 1e-6)
+        e = max(rel_err(y, yr), rel_err(mean, mr), rel_err(rstd, rr))
+        extra = None
+        if time_it:
+            us = timeit(lambda: native.layernorm_fwd(x, gamma, beta, 1e-6))
+            extra = {"us": round(us, 1), "GBps": round(4 * x.numel() / us / 1e3, 1)}
+        record(f"layernorm_fwd {tag}", e < 1e-2, e, extra)
+        dx, dg, db = native.layernorm_bwd(dy, x, mr, rr, gamma)
+        dxr, dgr, dbr = reference.layernorm_bwd(dy, x, mr, rr, gamma)
+        e = max(rel_err(dx, dxr), rel_err(dg, dgr), rel_err(db, dbr))
+        extra = None
+        if time_it:
+            us = timeit(lambda: native.layernorm_bwd(dy, x, mr, rr, gamma))
+            extra = {"us": round(us, 1), "GBps": round(6 * x.numel() / us / 1e3, 1)}
+        record(f"layernorm_bwd {tag}", e < 1e-2, e, extra)
+    run_case(f"layernorm {tag}", run)
+
+
 # ----------------------------------------------------------------------------- others
 def check_pool():
     for (B, C, H, W) in ((2, 64, 16, 16), (3, 64, 15, 17), (4, 64, 112, 112)):
@@ -360,6 +387,9 @@ def main():
             shapes += [(128, 64, 56, 56), (128, 256, 56, 56), (128, 512, 28, 28), (128, 2048, 7, 7)]
         for s in shapes:
             check_bn(*s, a.time)
+    if only is None or "ln" in only:
+        for shp in ((5, 768), (197 * 3 + 1, 256), (1030, 1024)) + (() if a.quick else ((128 * 197, 768),)):
+            check_layernorm(*shp, a.time)
     if only is None or "stem" in only:
         for shp in ((2, 32, 32), (3, 64, 48)) + (() if a.quick else ((128, 224, 224),)):
             check_stem(*shp, a.time)

@@ -490,6 +490,44 @@ std::tuple<Tensor, Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::opt
     return {dx, dres, sums};
 }
 
+// -------------------------------------------------------------------------------- layernorm
+std::tuple<Tensor, Tensor, Tensor> layernorm_fwd(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps) {
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kBFloat16 && x.is_contiguous() && x.dim() >= 2,
+                "layernorm_fwd: expected a contiguous bf16 GPU tensor [..., D]");
+    const long D = x.size(-1), M = x.numel() / D;
+    TORCH_CHECK(layernorm_dim_ok((int)D), "layernorm: unsupported width ", D);
+    TORCH_CHECK(reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0, "x must be 16-B aligned");
+    check_vec_f32(gamma, D, "gamma"); check_vec_f32(beta, D, "beta");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    Tensor y = at::empty_like(x);
+    Tensor mean = at::empty({M}, x.options().dtype(at::kFloat)), rstd = at::empty({M}, x.options().dtype(at::kFloat));
+    if (M > 0)
+        launch_layernorm_fwd(x.data_ptr(), gamma.data_ptr<float>(), beta.data_ptr<float>(), y.data_ptr(),
+                             mean.data_ptr<float>(), rstd.data_ptr<float>(), M, (int)D, (float)eps, cur_stream(x));
+    return {y, mean, rstd};
+}
+
+// -> (dx, dgamma, dbeta)
+std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& mean,
+                                                 const Tensor& rstd, const Tensor& gamma) {
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kBFloat16 && x.is_contiguous() && x.dim() >= 2, "x: contiguous bf16");
+    TORCH_CHECK(dy.is_cuda() && dy.scalar_type() == at::kBFloat16 && dy.is_contiguous() && dy.sizes() == x.sizes(),
+                "dy: contiguous bf16 with the shape of x");
+    const long D = x.size(-1), M = x.numel() / D;
+    TORCH_CHECK(layernorm_dim_ok((int)D), "layernorm: unsupported width ", D);
+    TORCH_CHECK(reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0 && reinterpret_cast<uintptr_t>(dy.data_ptr()) % 16 == 0,
+                "x / dy must be 16-B aligned");
+    check_vec_f32(gamma, D, "gamma"); check_vec_f32(mean, M, "mean"); check_vec_f32(rstd, M, "rstd");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    Tensor dx = at::empty_like(x);
+    const int blocks = layernorm_bwd_blocks(M);
+    Tensor slab = at::empty({blocks, 2 * D}, x.options().dtype(at::kFloat));
+    launch_layernorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
+                         gamma.data_ptr<float>(), dx.data_ptr(), slab.data_ptr<float>(), blocks, M, (int)D, cur_stream(x));
+    Tensor sums = blocks == 1 ? slab.view({2 * D}) : reduce_slab(slab, blocks, 2 * D);
+    return {dx, sums.narrow(0, D, D), sums.narrow(0, 0, D)};
+}
+
 // ------------------------------------------------------------------------------------ pools
 std::tuple<Tensor, Tensor> maxpool3x3s2_fwd(const Tensor& x) {
     check_nhwc_bf16(x, "x");
@@ -757,6 +795,8 @@ void bind_ops(pybind11::module& m) {
     m.def("bn_apply_act", &bn_apply_act);
     m.def("bn_bwd_reduce", &bn_bwd_reduce);
     m.def("bn_bwd_elemt", &bn_bwd_elemt);
+    m.def("layernorm_fwd", &layernorm_fwd);
+    m.def("layernorm_bwd", &layernorm_bwd);
     m.def("maxpool3x3s2_fwd", &maxpool3x3s2_fwd);
     m.def("maxpool3x3s2_bwd", &maxpool3x3s2_bwd);
     m.def("global_avgpool_fwd", &global_avgpool_fwd);

@@ -77,6 +77,15 @@ void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx,
                          int nps, float* sums_out /*[2][C] or null*/, float count, const float* count_dev, int relu,
                          hipStream_t s);
 
+// ---- LayerNorm over the last dim of [M, D] bf16 (layernorm.hip) -----------------------------------
+bool layernorm_dim_ok(int D);
+int layernorm_bwd_blocks(long M);  // rows of the dgamma / dbeta partial slab
+void launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                          long M, int D, float eps, hipStream_t s);
+// slab: fp32 [blocks][2][D] = per-block partial [dbeta, dgamma]
+void launch_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                          void* dx, float* slab, int blocks, long M, int D, hipStream_t s);
+
 // ---- pools (NHWC bf16) -----------------------------------------------------------------------
 void launch_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int B, int H, int W, int C, int Ho, int Wo,
                              hipStream_t s);

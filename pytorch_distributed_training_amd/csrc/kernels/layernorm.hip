@@ -1,0 +1,175 @@
+// LayerNorm over the last dimension for token-major activations [M, D] (ViT: D = 768), bf16 in / bf16 out,
+// fp32 statistics and affine parameters.
+//
+// One wave per row: D / 64 elements per lane as 8-byte (4 x bf16) pieces, so a row is read ONCE into
+// registers, mean and variance are two in-register passes (no E[x^2] - E[x]^2 cancellation) and the
+// normalised row is written straight back: 2 bytes read + 2 bytes written per element, against the
+// cast -> fp32 LayerNorm -> cast sequence (14 bytes per element) it replaces.
+// Backward: one pass for dx; the per-column dgamma / dbeta sums stay in registers across all rows a wave
+// visits (a lane always owns the same columns), are combined per block in LDS and written as partial
+// rows [blocks][2][D] that a fixed-order second launch sums (deterministic, no float atomics).
+#include "common.h"
+#include "kernels.h"
+
+namespace pdt {
+namespace {
+
+constexpr int kMaxPieces = 16;  // D <= 4096
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_ln_fwd(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, bf16* __restrict__ y,
+                                                float* __restrict__ mean_out, float* __restrict__ rstd_out, long M,
+                                                float eps) {
+    constexpr int D = NP * 256;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16x4* xr = reinterpret_cast<const bf16x4*>(x + row * D);
+    float v[NP][4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const bf16x4 t = xr[lane + 64 * j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[j][k] = (float)t[k];
+            s += v[j][k];
+        }
+    }
+    const float mean = wave_sum(s) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = v[j][k] - mean;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + eps);
+    bf16x4* yr = reinterpret_cast<bf16x4*>(y + row * D);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[lane + 64 * j];
+        const f32x4 b = reinterpret_cast<const f32x4*>(beta)[lane + 64 * j];
+        bf16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (bf16)((v[j][k] - mean) * rstd * g[k] + b[k]);
+        yr[lane + 64 * j] = o;
+    }
+    if (lane == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = rstd;
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                const float* __restrict__ gamma, bf16* __restrict__ dx,
+                                                float* __restrict__ slab /*[gridDim.x][2][D]*/, long M) {
+    constexpr int D = NP * 256;
+    __shared__ float red[3][2][D];  // waves 1..3 park their column sums here
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NP][4], dgam[NP][4], dbet[NP][4];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const f32x4 t = reinterpret_cast<const f32x4*>(gamma)[lane + 64 * j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            g[j][k] = t[k];
+            dgam[j][k] = 0.f;
+            dbet[j][k] = 0.f;
+        }
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+        const bf16x4* xr = reinterpret_cast<const bf16x4*>(x + row * D);
+        const bf16x4* dr = reinterpret_cast<const bf16x4*>(dy + row * D);
+        const float mu = mean[row], rs = rstd[row];
+        float xh[NP][4], gg[NP][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const bf16x4 tx = xr[lane + 64 * j];
+            const bf16x4 td = dr[lane + 64 * j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = (float)td[k];
+                xh[j][k] = ((float)tx[k] - mu) * rs;
+                gg[j][k] = d * g[j][k];
+                s1 += gg[j][k];
+                s2 += gg[j][k] * xh[j][k];
+                dgam[j][k] += d * xh[j][k];
+                dbet[j][k] += d;
+            }
+        }
+        const float c1 = wave_sum(s1) * (1.f / D), c2 = wave_sum(s2) * (1.f / D);
+        bf16x4* ox = reinterpret_cast<bf16x4*>(dx + row * D);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (bf16)(rs * (gg[j][k] - c1 - xh[j][k] * c2));
+            ox[lane + 64 * j] = o;
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                red[wave - 1][0][(lane + 64 * j) * 4 + k] = dbet[j][k];
+                red[wave - 1][1][(lane + 64 * j) * 4 + k] = dgam[j][k];
+            }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = slab + (long)blockIdx.x * 2 * D;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            f32x4 ob, og;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = (lane + 64 * j) * 4 + k;
+                ob[k] = dbet[j][k] + red[0][0][c] + red[1][0][c] + red[2][0][c];
+                og[k] = dgam[j][k] + red[0][1][c] + red[1][1][c] + red[2][1][c];
+            }
+            reinterpret_cast<f32x4*>(out)[lane + 64 * j] = ob;
+            reinterpret_cast<f32x4*>(out + D)[lane + 64 * j] = og;
+        }
+    }
+}
+
+}  // namespace
+
+bool layernorm_dim_ok(int D) { return D == 256 || D == 512 || D == 768 || D == 1024 || D == 1280; }
+
+int layernorm_bwd_blocks(long M) {
+    long b = (M + 3) / 4;
+    return (int)(b < 512 ? b : 512);
+}
+
+#define PDT_LN_DISPATCH(D, CALL)                        \
+    switch (D) {                                        \
+        case 256: { constexpr int NP = 1; CALL; } break;  \
+        case 512: { constexpr int NP = 2; CALL; } break;  \
+        case 768: { constexpr int NP = 3; CALL; } break;  \
+        case 1024: { constexpr int NP = 4; CALL; } break; \
+        case 1280: { constexpr int NP = 5; CALL; } break; \
+        default: abort();                               \
+    }
+
+void launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                          long M, int D, float eps, hipStream_t s) {
+    const unsigned grid = (unsigned)((M + 3) / 4);
+    PDT_LN_DISPATCH(D, hipLaunchKernelGGL((k_ln_fwd<NP>), dim3(grid), dim3(256), 0, s, (const bf16*)x, gamma, beta,
+                                          (bf16*)y, mean, rstd, M, eps));
+}
+
+void launch_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                          void* dx, float* slab, int blocks, long M, int D, hipStream_t s) {
+    PDT_LN_DISPATCH(D, hipLaunchKernelGGL((k_ln_bwd<NP>), dim3(blocks), dim3(256), 0, s, (const bf16*)dy,
+                                          (const bf16*)x, mean, rstd, gamma, (bf16*)dx, slab, M));
+}
+
+}  // namespace pdt

@@ -20,6 +20,7 @@ import torch.nn as tnn
 import torch.nn.functional as tF
 
 from .. import nn as pnn
+from ..nn.functional import layer_norm
 
 
 class MultiheadSelfAttention(tnn.Module):
@@ -44,8 +45,9 @@ class MultiheadSelfAttention(tnn.Module):
             qkv = tF.linear(x, w, bias)
         qkv = qkv.view(b, s, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]  # [b, h, s, hd]
-        att = torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(self.head_dim))
-        att = torch.softmax(att.float(), dim=-1).to(x.dtype)
+        # scale the [b,h,s,64] operand, not the [b,h,s,s] scores; softmax accumulates in fp32 in one pass
+        att = torch.matmul(q * (1.0 / math.sqrt(self.head_dim)), k.transpose(-1, -2))
+        att = torch.softmax(att, dim=-1, dtype=torch.float32).to(x.dtype)
         out = torch.matmul(att, v).transpose(1, 2).reshape(b, s, d)
         return self.out_proj(out)
 
@@ -65,7 +67,7 @@ class EncoderBlock(tnn.Module):
 
     @staticmethod
     def _ln(ln, x):
-        return tF.layer_norm(x.float(), ln.normalized_shape, ln.weight.float(), ln.bias.float(), ln.eps).to(x.dtype)
+        return layer_norm(x, ln.weight, ln.bias, ln.eps)
 
     def forward(self, x):
         y = self.dropout(self.self_attention(self._ln(self.ln_1, x)))
@@ -107,8 +109,18 @@ class VisionTransformer(tnn.Module):
 
     def forward(self, x):
         b = x.shape[0]
-        x = self.conv_proj(x)  # [b, dim, h/p, w/p]
-        x = x.flatten(2).transpose(1, 2)  # [b, tokens, dim]
+        # patch embedding: a stride = kernel conv is a GEMM over unfolded patches ([b*tokens, 3*p*p] x W^T);
+        # it goes to the plain library GEMM instead of a convolution library
+        p, g = self.patch_size, self.image_size // self.patch_size
+        patches = x.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
+        w = self.conv_proj.weight
+        w2 = w.reshape(self.hidden_dim, -1)
+        w_lp = getattr(w, "_lp", None)
+        if w.dtype != patches.dtype:
+            x = pnn.modules._LowpLinearFn.apply(patches, w2, self.conv_proj.bias,
+                                               None if w_lp is None else w_lp.reshape(self.hidden_dim, -1))
+        else:
+            x = tF.linear(patches, w2, self.conv_proj.bias)  # [b, tokens, dim]
         x = torch.cat([self.class_token.to(x.dtype).expand(b, -1, -1), x], dim=1)
         x = self.encoder(x)
         return self.heads(x[:, 0])

@@ -192,6 +192,37 @@ def bn_act(x, gamma, beta, cfg: BNConfig, residual=None, relu: bool = False, sta
     return _BNActFn.apply(x, gamma, beta, residual, stats, cfg, bool(relu))
 
 
+# ---------------------------------------------------------------- layernorm
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        be = backend_for(x)
+        if be is not reference:
+            why = be.layernorm_unsupported_reason(x)
+            if why is not None:
+                _note_fallback("layer_norm", why)
+                be = reference
+        x = x.contiguous()
+        g32, b32 = gamma.float(), beta.float()
+        y, mean, rstd = be.layernorm_fwd(x, g32, b32, eps)
+        ctx.save_for_backward(x, mean, rstd, g32)
+        ctx.cfg = (be, gamma.dtype, beta.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, g32 = ctx.saved_tensors
+        be, gdt, bdt = ctx.cfg
+        dx, dgamma, dbeta = be.layernorm_bwd(dy, x, mean, rstd, g32)
+        return dx, dgamma.to(gdt), dbeta.to(bdt), None
+
+
+def layer_norm(x, weight, bias, eps: float = 1e-5):
+    """LayerNorm over the last dimension: one read + one write of the activation in its own dtype, fp32
+    statistics (HIP kernel on bf16 GPU tensors, PyTorch fp32 oracle elsewhere)."""
+    return _LayerNormFn.apply(x, weight, bias, float(eps))
+
+
 # -------------------------------------------------------------------- pools
 class _MaxPool3x3s2Fn(torch.autograd.Function):
     @staticmethod

@@ -72,7 +72,7 @@ class _LowpLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = (dy2.t() @ x2).to(ctx.wdt)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.float().sum(0).to(ctx.wdt)
+            db = dy2.sum(0, dtype=torch.float32).to(ctx.wdt)  # fp32 accumulation without a separate cast pass
         return dx, dw, db, None
 
 

@@ -168,6 +168,25 @@ def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, psums, count, relu: bool, want_d
     return dx, (dres if want_dres else None), sums
 
 
+# ---------------------------------------------------------------- layernorm
+def layernorm_unsupported_reason(x):
+    if x.dtype != _BF16:
+        return f"dtype {x.dtype} (native LayerNorm is bf16)"
+    if x.shape[-1] not in (256, 512, 768, 1024, 1280):
+        return f"width {x.shape[-1]}"
+    return None
+
+
+def layernorm_fwd(x, gamma, beta, eps: float):
+    """-> (y, mean, rstd) over the last dimension"""
+    return _C.layernorm_fwd(x.contiguous(), gamma.contiguous(), beta.contiguous(), eps)
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma):
+    """-> (dx, dgamma, dbeta)"""
+    return _C.layernorm_bwd(dy.contiguous(), x, mean, rstd, gamma.contiguous())
+
+
 # -------------------------------------------------------------------- pools
 def maxpool3x3s2_fwd(x):
     """-> (y, argmax taps as uint8 [B,Ho,Wo,C])"""

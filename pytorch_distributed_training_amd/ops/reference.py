@@ -116,6 +116,27 @@ def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, psums, count, relu: bool, want_d
     return dx.to(x.dtype), dres, sums
 
 
+# ------------------------------------------------------------ layernorm ----
+def layernorm_fwd(x, gamma, beta, eps: float):
+    xf = x.float()
+    mean = xf.mean(-1)
+    var = xf.var(-1, unbiased=False)
+    rstd = torch.rsqrt(var + eps)
+    y = (xf - mean[..., None]) * rstd[..., None] * gamma + beta
+    return y.to(x.dtype), mean.reshape(-1), rstd.reshape(-1)
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma):
+    d = x.shape[-1]
+    xf, dyf = x.float().reshape(-1, d), dy.float().reshape(-1, d)
+    xhat = (xf - mean[:, None]) * rstd[:, None]
+    g = dyf * gamma
+    c1 = g.mean(-1, keepdim=True)
+    c2 = (g * xhat).mean(-1, keepdim=True)
+    dx = rstd[:, None] * (g - c1 - xhat * c2)
+    return dx.to(x.dtype).view_as(x), (dyf * xhat).sum(0), dyf.sum(0)
+
+
 # ---------------------------------------------------------------- pools ----
 def maxpool3x3s2_fwd(x):
     """-> (y, aux); the oracle needs no aux"""

@@ -61,6 +61,13 @@ def test_conv_kernels_fwd_dgrad_wgrad(kc, case):
     _assert_all_ok(kc, n)
 
 
+@pytest.mark.parametrize("shape", [(5, 768), (592, 256), (1030, 1024), (8 * 197, 768)])
+def test_layernorm_kernels(kc, shape):
+    n = len(kc.RESULTS)
+    kc.check_layernorm(*shape, False)
+    _assert_all_ok(kc, n)
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 32), (3, 64, 48), (4, 224, 224)])
 def test_stem_conv_native_fwd_wgrad(kc, shape):
     n = len(kc.RESULTS)

@@ -307,3 +307,22 @@ def test_native_extension_builds_and_imports():
         assert hasattr(ext, name)
     plan = ext.plan_buckets([10, 300, 5], [2, 1, 0], 4, 1 << 20, 1 << 10)
     assert [p[0] for p in plan] == [[2], [1, 0]] or [p[0] for p in plan] == [[2, 1], [0]] or len(plan) >= 1
+
+
+def test_layer_norm_function_matches_torch_autograd():
+    from pytorch_distributed_training_amd.nn.functional import layer_norm
+
+    torch.manual_seed(0)
+    x = torch.randn(3, 7, 32, requires_grad=True)
+    w = torch.rand(32, requires_grad=True)
+    b = torch.randn(32, requires_grad=True)
+    dy = torch.randn(3, 7, 32)
+    y = layer_norm(x, w, b, 1e-6)
+    y.backward(dy)
+    got = [y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone()]
+    for t in (x, w, b):
+        t.grad = None
+    yr = torch.nn.functional.layer_norm(x, (32,), w, b, 1e-6)
+    yr.backward(dy)
+    for a, r in zip(got, [yr.detach(), x.grad, w.grad, b.grad]):
+        assert torch.allclose(a, r, rtol=1e-4, atol=1e-5)
