@@ -248,6 +248,31 @@ def check_bn(B, C, H, W, time_it):
     run_case(f"bn_bwd {tag}", bwd)
 
 
+def check_attention(B, S, H, time_it):
+    tag = f"B{B} S{S} H{H}"
+    qkv = torch.randn(B, S, 3 * H * 64, device=DEV).to(torch.bfloat16)
+    dout = torch.randn(B, S, H * 64, device=DEV).to(torch.bfloat16)
+
+    def run():
+        out, lse = native.attention_fwd(qkv, H)
+        outr, lser = reference.attention_fwd(qkv.float(), H)
+        e = max(rel_err(out, outr), rel_err(lse, lser))
+        extra = None
+        if time_it:
+            extra = {"us": round(timeit(lambda: native.attention_fwd(qkv, H)), 1)}
+        record(f"attention_fwd {tag}", e < 2e-2, e, extra)
+        dqkv = native.attention_bwd(dout, qkv, out, lse, H)
+        dr = reference.attention_bwd(dout.float(), qkv.float(), outr, lser, H)
+        d = 3 * H * 64
+        parts = {"dq": slice(0, d // 3), "dk": slice(d // 3, 2 * d // 3), "dv": slice(2 * d // 3, d)}
+        errs = {k: rel_err(dqkv[..., sl], dr[..., sl]) for k, sl in parts.items()}
+        extra = dict(errs)
+        if time_it:
+            extra["us"] = round(timeit(lambda: native.attention_bwd(dout, qkv, out, lse, H)), 1)
+        record(f"attention_bwd {tag}", max(errs.values()) < 3e-2, max(errs.values()), extra)
+    run_case(f"attention {tag}", run)
+
+
 def check_layernorm(M, D, time_it):
     tag = f"M{M} D{D}"
     x = (torch.randn(M, D, device=DEV) * 2 + 0.3).to(torch.bfloat16)
@@ -387,6 +412,9 @@ def main():
             shapes += [(128, 64, 56, 56), (128, 256, 56, 56), (128, 512, 28, 28), (128, 2048, 7, 7)]
         for s in shapes:
             check_bn(*s, a.time)
+    if only is None or "attn" in only:
+        for shp in ((2, 32, 1), (3, 197, 2), (2, 50, 3), (1, 256, 2), (2, 17, 1)) + (() if a.quick else ((128, 197, 12),)):
+            check_attention(*shp, a.time)
     if only is None or "ln" in only:
         for shp in ((5, 768), (197 * 3 + 1, 256), (1030, 1024)) + (() if a.quick else ((128 * 197, 768),)):
             check_layernorm(*shp, a.time)

@@ -528,6 +528,45 @@ std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& dy, const Tensor&
     return {dx, sums.narrow(0, D, D), sums.narrow(0, 0, D)};
 }
 
+// -------------------------------------------------------------------------------- attention
+void check_attn(const Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kBFloat16 && t.is_contiguous() && t.dim() == 3, name,
+                ": expected a contiguous bf16 GPU tensor [B, S, width]");
+    TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, ": data pointer must be 16-B aligned");
+}
+
+// qkv [B, S, 3*H*64] (packed q | k | v, heads inside) -> (out [B, S, H*64], lse [B, H, S])
+std::tuple<Tensor, Tensor> attention_fwd(const Tensor& qkv, int64_t heads) {
+    check_attn(qkv, "qkv");
+    const long B = qkv.size(0), S = qkv.size(1), D = qkv.size(2) / 3;
+    TORCH_CHECK(qkv.size(2) == 3 * D && heads > 0 && D == heads * 64, "attention: width must be 3 * heads * 64");
+    TORCH_CHECK(attention_shape_ok((int)S, 64), "attention: sequence length ", S, " not supported (<= 256)");
+    TORCH_CHECK(B * heads < (1L << 31), "too many (batch, head) pairs");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
+    Tensor out = at::empty({B, S, D}, qkv.options());
+    Tensor lse = at::empty({B, heads, S}, qkv.options().dtype(at::kFloat));
+    if (B > 0)
+        launch_attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr<float>(), (int)B, (int)S, (int)heads,
+                             cur_stream(qkv));
+    return {out, lse};
+}
+
+Tensor attention_bwd(const Tensor& dout, const Tensor& qkv, const Tensor& out, const Tensor& lse, int64_t heads) {
+    check_attn(qkv, "qkv"); check_attn(out, "out"); check_attn(dout, "dout");
+    const long B = qkv.size(0), S = qkv.size(1), D = qkv.size(2) / 3;
+    TORCH_CHECK(qkv.size(2) == 3 * D && D == heads * 64, "attention: width must be 3 * heads * 64");
+    TORCH_CHECK(out.size(0) == B && out.size(1) == S && out.size(2) == D && dout.sizes() == out.sizes(), "out / dout shape");
+    TORCH_CHECK(lse.is_cuda() && lse.scalar_type() == at::kFloat && lse.is_contiguous() && lse.numel() == B * heads * S,
+                "lse: expected contiguous fp32 [B, H, S]");
+    TORCH_CHECK(attention_shape_ok((int)S, 64), "attention: sequence length ", S, " not supported (<= 256)");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
+    Tensor dqkv = at::empty_like(qkv);
+    if (B > 0)
+        launch_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr<float>(), dqkv.data_ptr(),
+                             (int)B, (int)S, (int)heads, cur_stream(qkv));
+    return dqkv;
+}
+
 // ------------------------------------------------------------------------------------ pools
 std::tuple<Tensor, Tensor> maxpool3x3s2_fwd(const Tensor& x) {
     check_nhwc_bf16(x, "x");
@@ -795,6 +834,8 @@ void bind_ops(pybind11::module& m) {
     m.def("bn_apply_act", &bn_apply_act);
     m.def("bn_bwd_reduce", &bn_bwd_reduce);
     m.def("bn_bwd_elemt", &bn_bwd_elemt);
+    m.def("attention_fwd", &attention_fwd);
+    m.def("attention_bwd", &attention_bwd);
     m.def("layernorm_fwd", &layernorm_fwd);
     m.def("layernorm_bwd", &layernorm_bwd);
     m.def("maxpool3x3s2_fwd", &maxpool3x3s2_fwd);

@@ -23,7 +23,7 @@ BUILD = os.path.join(HERE, "_build")
 ARCH = "gfx950"
 
 HIP_SOURCES = [
-    "kernels/elementwise.hip", "kernels/softmax_ce.hip", "kernels/bn.hip", "kernels/layernorm.hip", "kernels/pool.hip",
+    "kernels/elementwise.hip", "kernels/softmax_ce.hip", "kernels/bn.hip", "kernels/layernorm.hip", "kernels/attention.hip", "kernels/pool.hip",
     "kernels/conv_igemm.hip", "kernels/conv_wgrad.hip", "kernels/conv_wgrad_win.hip", "kernels/conv_stem.hip",
 ]
 CPP_SOURCES = ["binding/ops.cpp", "binding/module.cpp", "comm/rccl_comm.cpp", "reducer/reducer.cpp"]

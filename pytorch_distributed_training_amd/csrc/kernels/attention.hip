@@ -1,0 +1,376 @@
+// Fused multi-head self-attention (forward + backward) for short sequences on the gfx950 matrix cores.
+// ViT: 197 tokens, head_dim 64, no mask, no dropout.
+//
+//   qkv : [B, S, 3, H, 64] bf16  (the packed in-projection output, read in place: no permute copies)
+//   out : [B, S, H, 64]    bf16  (= [B, S, D], what the out-projection GEMM wants)
+//   lse : [B, H, S]        fp32  (log-sum-exp of the scaled scores, for the backward pass)
+//
+// One workgroup (4 waves) per (batch, head).  A whole head fits on chip: K, V (and Q, dO in the backward)
+// live in LDS as [SP][64] bf16 images (SP = S rounded up to 32), the S x S score matrix only ever exists
+// as MFMA accumulators: no [B,H,S,S] tensor touches HBM (the unfused path moves ~10 of them per layer).
+//
+//  * MFMA 32x32x16 bf16.  Scores are produced TRANSPOSED where that puts the softmax row in a lane
+//    (forward, dQ pass: S^T = K Q^T, lane = query) so row max / sum are in-register reductions plus one
+//    cross-half shuffle, and NON-transposed where the next GEMM contracts over queries (dK / dV pass).
+//  * An accumulator tile feeds the next MFMA straight from registers as its A operand: the C layout gives
+//    a lane the contraction indices (j&3) + 8*(j>>2) + 4*half of a 16-block, a permutation of the
+//    8*half + j the A operand nominally wants; the B operand is fetched with the same permutation
+//    (two ds_read_b64_tr_b16 at rows 4*half and 8 + 4*half), so no shuffles and no LDS round trip.
+//  * one LDS swizzle serves both fragment kinds (16-B ds_read_b128 rows and transposing 8-B reads):
+//    chunk ^= ((row>>1)&1)<<2 | ((row>>2)&3).
+//  * softmax scale 1/8 is folded into Q when it is staged (exact in bf16).
+//  * deterministic: no atomics; the backward recomputes the scores once per pass (dK/dV pass with a wave
+//    per key tile, dQ pass with a wave per query tile) instead of reducing dQ across waves.
+#include "common.h"
+#include "kernels.h"
+
+namespace pdt {
+namespace {
+
+constexpr int HD = 64;        // head dim
+constexpr int ROWB = HD * 2;  // LDS row bytes
+constexpr float kNegBig = -1e30f;  // finite stand-in for -inf (the kernels are built with -ffast-math)
+
+typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+
+__device__ __forceinline__ int swz(int row, int chunk) {
+    const int x = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    return row * ROWB + ((chunk ^ x) << 4);
+}
+// MFMA A/B fragment whose contraction index runs along the 64-wide dim of a row-major [row][64] image:
+// lane = row (l&31), elements d = 16*step + 8*(l>>5) + 0..7
+__device__ __forceinline__ bf16x8 frag_rows(const char* img, int row, int step, int half) {
+    return *reinterpret_cast<const bf16x8*>(img + swz(row, 2 * step + half));
+}
+// MFMA B fragment whose contraction index runs along the ROWS of a row-major [row][64] image, in the
+// permuted order of an accumulator tile used as A operand: lane col = colbase + (l&31), contraction
+// j<4 -> row r0 + 4*half + j, j>=4 -> row r0 + 8 + 4*half + (j-4)
+__device__ __forceinline__ bf16x8 frag_cols(const char* img, int r0, int colbase, int lane) {
+    const int q4 = (lane & 15) >> 2, p = lane & 3, h16 = (lane >> 4) & 1, half = lane >> 5;
+    const int col = colbase + h16 * 16 + p * 4;
+    const int ra = r0 + 4 * half + q4, rb = ra + 8;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + swz(ra, col >> 3) + (col & 7) * 2));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + swz(rb, col >> 3) + (col & 7) * 2));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// accumulator tile regs [8*blk, 8*blk+8) -> bf16 A operand
+__device__ __forceinline__ bf16x8 acc_to_a(const f32x16& t, int blk) {
+    bf16x8 a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (bf16)t[8 * blk + j];
+    return a;
+}
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// stage rows [0, SP) of one of q/k/v (which = 0/1/2) or of a [B,S,H,64] tensor (which < 0) into an LDS image
+template <int NT>
+__device__ __forceinline__ void stage(char* img, const bf16* src, long row_stride, int S, float scale, int tid) {
+    constexpr int SP = NT * 32;
+    for (int i = tid; i < SP * 8; i += 256) {
+        const int row = i >> 3, ch = i & 7;
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (bf16)0.f;
+        if (row < S) v = *reinterpret_cast<const bf16x8*>(src + (long)row * row_stride + ch * 8);
+        if (scale != 1.f) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] * scale);
+        }
+        *reinterpret_cast<bf16x8*>(img + swz(row, ch)) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <int NT>
+__global__ __launch_bounds__(256) void k_attn_fwd(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                  float* __restrict__ lse, int S, int H) {
+    constexpr int SP = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + SP * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const long D = (long)H * HD, rs = 3 * D;
+    const bf16* base = qkv + (long)b * S * rs + h * HD;
+    stage<NT>(Ks, base + D, rs, S, 1.f, tid);
+    stage<NT>(Vs, base + 2 * D, rs, S, 1.f, tid);
+    __syncthreads();
+
+    for (int qt = wave; qt < NT; qt += 4) {
+        // Q fragments straight from global (each query row is used by this wave only), scaled by 1/8
+        const int q = qt * 32 + l31;
+        bf16x8 bq[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bq[s][k] = (bf16)0.f;
+            if (q < S) {
+                bq[s] = *reinterpret_cast<const bf16x8*>(base + (long)q * rs + s * 16 + half * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bq[s][k] = (bf16)((float)bq[s][k] * 0.125f);
+            }
+        }
+        // S^T tiles: rows = keys, lane = query
+        f32x16 st[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32 + l31, s, half), bq[s], st[kt], 0, 0, 0);
+        }
+        float m = kNegBig;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (kt * 32 + acc_row(r, half) >= S) st[kt][r] = kNegBig;
+                m = fmaxf(m, st[kt][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(st[kt][r] - m);
+                st[kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        // O = P V
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const bf16x8 pa = acc_to_a(st[kt], blk);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_cols(Vs, kt * 32 + blk * 16, dt * 32, lane),
+                                                                   o[dt], 0, 0, 0);
+            }
+        const float inv = 1.f / sum;
+        if (q < S && half == 0) lse[((long)b * H + h) * S + q] = m + __logf(sum);
+        // o rows are queries (acc_row), this lane's 1/sum belongs to query l31: fetch the row's value
+        bf16* orow = out + ((long)b * S * H + h) * HD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = acc_row(r, half);
+            const float invr = __shfl(inv, qr, 64);
+            const int qq = qt * 32 + qr;
+            if (qq < S) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) orow[(long)qq * D + dt * 32 + l31] = (bf16)(o[dt][r] * invr);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------- backward
+template <int NT>
+__global__ __launch_bounds__(256) void k_attn_bwd(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                  const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                  bf16* __restrict__ dqkv, int S, int H) {
+    constexpr int SP = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;                       // scaled by 1/8
+    char* Ks = Qs + SP * ROWB;
+    char* Vs = Ks + SP * ROWB;
+    char* Os = Vs + SP * ROWB;             // dO
+    float* Ls = reinterpret_cast<float*>(Os + SP * ROWB);  // lse[q]   (huge on padding rows: P = 0 there)
+    float* Ds = Ls + SP;                                   // D[q] = sum_d dO * O
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const long D = (long)H * HD, rs = 3 * D;
+    const bf16* base = qkv + (long)b * S * rs + h * HD;
+    const bf16* obase = out + ((long)b * S * H + h) * HD;
+    const bf16* dobase = dout + ((long)b * S * H + h) * HD;
+    stage<NT>(Qs, base, rs, S, 0.125f, tid);
+    stage<NT>(Ks, base + D, rs, S, 1.f, tid);
+    stage<NT>(Vs, base + 2 * D, rs, S, 1.f, tid);
+    stage<NT>(Os, dobase, D, S, 1.f, tid);
+    if (tid < SP) {
+        float d = 0.f, l = -kNegBig;
+        if (tid < S) {
+            l = lse[((long)b * H + h) * S + tid];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(obase + (long)tid * D + c * 8);
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(dobase + (long)tid * D + c * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d += (float)a[k] * (float)g[k];
+            }
+        }
+        Ls[tid] = l;
+        Ds[tid] = d;
+    }
+    __syncthreads();
+    bf16* dq_base = dqkv + (long)b * S * rs + h * HD;
+
+    // ---- pass A: a wave owns a KEY tile; scores non-transposed (lane = key, regs = queries) -> dK, dV
+    for (int kt = wave; kt < NT; kt += 4) {
+        const int key = kt * 32 + l31;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = frag_rows(Ks, key, s, half);
+            vf[s] = frag_rows(Vs, key, s, half);
+        }
+        f32x16 dk[2], dv[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dk[dt][r] = 0.f;
+                dv[dt][r] = 0.f;
+            }
+        for (int qt = 0; qt < NT; ++qt) {
+            f32x16 sc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = 0.f;
+                dp[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, qt * 32 + l31, s, half), kf[s], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Os, qt * 32 + l31, s, half), vf[s], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qt * 32 + acc_row(r, half);
+                const float p = key < S ? __expf(sc[r] - Ls[q]) : 0.f;
+                sc[r] = p;                    // P
+                dp[r] = p * (dp[r] - Ds[q]);  // dS
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const bf16x8 pa = acc_to_a(sc, blk), dsa = acc_to_a(dp, blk);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_cols(Os, qt * 32 + blk * 16, dt * 32, lane),
+                                                                    dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, frag_cols(Qs, qt * 32 + blk * 16, dt * 32, lane),
+                                                                    dk[dt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = kt * 32 + acc_row(r, half);
+            if (kk < S) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dq_base[(long)kk * rs + D + dt * 32 + l31] = (bf16)dk[dt][r];       // Qs carries the 1/8
+                    dq_base[(long)kk * rs + 2 * D + dt * 32 + l31] = (bf16)dv[dt][r];
+                }
+            }
+        }
+    }
+
+    // ---- pass B: a wave owns a QUERY tile; scores transposed (lane = query, regs = keys) -> dQ
+    for (int qt = wave; qt < NT; qt += 4) {
+        const int q = qt * 32 + l31;
+        bf16x8 qf[4], gf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = frag_rows(Qs, q, s, half);
+            gf[s] = frag_rows(Os, q, s, half);
+        }
+        const float lq = Ls[q], dq_row = Ds[q];
+        f32x16 dq[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x16 sc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = 0.f;
+                dp[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32 + l31, s, half), qf[s], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, kt * 32 + l31, s, half), gf[s], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kt * 32 + acc_row(r, half);
+                const float p = kk < S ? __expf(sc[r] - lq) : 0.f;
+                dp[r] = p * (dp[r] - dq_row);
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const bf16x8 dsa = acc_to_a(dp, blk);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, frag_cols(Ks, kt * 32 + blk * 16, dt * 32, lane),
+                                                                    dq[dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = qt * 32 + acc_row(r, half);
+            if (qq < S) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) dq_base[(long)qq * rs + dt * 32 + l31] = (bf16)(dq[dt][r] * 0.125f);
+            }
+        }
+    }
+}
+
+template <typename K>
+void set_lds(K kern, size_t bytes) {
+    PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)bytes));
+}
+
+}  // namespace
+
+bool attention_shape_ok(int S, int head_dim) { return head_dim == HD && S >= 1 && S <= 256; }
+
+void launch_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, hipStream_t s) {
+    const int nt = (S + 31) / 32;
+    const size_t lds = (size_t)2 * nt * 32 * ROWB;
+#define PDT_ATTN_FWD(N)                                                                                        \
+    case N: {                                                                                                  \
+        static bool once = (set_lds(&k_attn_fwd<N>, lds), true);                                               \
+        (void)once;                                                                                            \
+        hipLaunchKernelGGL((k_attn_fwd<N>), dim3(B * H), dim3(256), lds, s, (const bf16*)qkv, (bf16*)out, lse, S, H); \
+    } break;
+    switch (nt) {
+        PDT_ATTN_FWD(1) PDT_ATTN_FWD(2) PDT_ATTN_FWD(3) PDT_ATTN_FWD(4) PDT_ATTN_FWD(5) PDT_ATTN_FWD(6) PDT_ATTN_FWD(7)
+        PDT_ATTN_FWD(8)
+        default: abort();
+    }
+#undef PDT_ATTN_FWD
+}
+
+void launch_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
+                          int S, int H, hipStream_t s) {
+    const int nt = (S + 31) / 32;
+    const size_t lds = (size_t)4 * nt * 32 * ROWB + (size_t)2 * nt * 32 * sizeof(float);
+#define PDT_ATTN_BWD(N)                                                                                      \
+    case N: {                                                                                                \
+        static bool once = (set_lds(&k_attn_bwd<N>, lds), true);                                             \
+        (void)once;                                                                                          \
+        hipLaunchKernelGGL((k_attn_bwd<N>), dim3(B * H), dim3(256), lds, s, (const bf16*)qkv, (const bf16*)out, \
+                           (const bf16*)dout, lse, (bf16*)dqkv, S, H);                                       \
+    } break;
+    switch (nt) {
+        PDT_ATTN_BWD(1) PDT_ATTN_BWD(2) PDT_ATTN_BWD(3) PDT_ATTN_BWD(4) PDT_ATTN_BWD(5) PDT_ATTN_BWD(6) PDT_ATTN_BWD(7)
+        PDT_ATTN_BWD(8)
+        default: abort();
+    }
+#undef PDT_ATTN_BWD
+}
+
+}  // namespace pdt

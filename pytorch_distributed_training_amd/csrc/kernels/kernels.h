@@ -86,6 +86,13 @@ void launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, 
 void launch_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                           void* dx, float* slab, int blocks, long M, int D, hipStream_t s);
 
+// ---- fused self-attention, head_dim 64, S <= 256 (attention.hip) -----------------------------------
+bool attention_shape_ok(int S, int head_dim);
+// qkv [B,S,3,H,64] bf16 -> out [B,S,H,64] bf16, lse [B,H,S] fp32
+void launch_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, hipStream_t s);
+void launch_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
+                          int S, int H, hipStream_t s);
+
 // ---- pools (NHWC bf16) -----------------------------------------------------------------------
 void launch_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int B, int H, int W, int C, int Ho, int Wo,
                              hipStream_t s);

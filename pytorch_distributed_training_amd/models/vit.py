@@ -20,7 +20,7 @@ import torch.nn as tnn
 import torch.nn.functional as tF
 
 from .. import nn as pnn
-from ..nn.functional import layer_norm
+from ..nn.functional import attention, layer_norm
 
 
 class MultiheadSelfAttention(tnn.Module):
@@ -43,12 +43,7 @@ class MultiheadSelfAttention(tnn.Module):
             qkv = pnn.modules._LowpLinearFn.apply(x, w, bias, getattr(w, "_lp", None))
         else:
             qkv = tF.linear(x, w, bias)
-        qkv = qkv.view(b, s, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
-        q, k, v = qkv[0], qkv[1], qkv[2]  # [b, h, s, hd]
-        # scale the [b,h,s,64] operand, not the [b,h,s,s] scores; softmax accumulates in fp32 in one pass
-        att = torch.matmul(q * (1.0 / math.sqrt(self.head_dim)), k.transpose(-1, -2))
-        att = torch.softmax(att, dim=-1, dtype=torch.float32).to(x.dtype)
-        out = torch.matmul(att, v).transpose(1, 2).reshape(b, s, d)
+        out = attention(qkv, self.num_heads)  # [b, s, d]: fused kernel on GPU/bf16, matmul-softmax oracle elsewhere
         return self.out_proj(out)
 
 

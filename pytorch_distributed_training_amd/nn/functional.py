@@ -192,6 +192,36 @@ def bn_act(x, gamma, beta, cfg: BNConfig, residual=None, relu: bool = False, sta
     return _BNActFn.apply(x, gamma, beta, residual, stats, cfg, bool(relu))
 
 
+# ---------------------------------------------------------------- attention
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        be = backend_for(qkv)
+        if be is not reference:
+            why = be.attention_unsupported_reason(qkv, heads)
+            if why is not None:
+                _note_fallback("attention", why)
+                be = reference
+        qkv = qkv.contiguous()
+        out, lse = be.attention_fwd(qkv, heads)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (be, heads)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        be, heads = ctx.cfg
+        return be.attention_bwd(dout, qkv, out, lse, heads), None
+
+
+def attention(qkv, heads: int):
+    """Multi-head self-attention on the packed in-projection output ``[B, S, 3*D]`` (q | k | v, heads inside
+    each) -> ``[B, S, D]``; scale 1/sqrt(head_dim), no mask, no dropout.  On bf16 GPU tensors with head_dim 64
+    one fused HIP kernel per direction keeps the S x S scores on chip."""
+    return _AttentionFn.apply(qkv, int(heads))
+
+
 # ---------------------------------------------------------------- layernorm
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod

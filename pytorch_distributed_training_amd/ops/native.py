@@ -168,6 +168,26 @@ def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, psums, count, relu: bool, want_d
     return dx, (dres if want_dres else None), sums
 
 
+# ---------------------------------------------------------------- attention
+def attention_unsupported_reason(qkv, heads: int):
+    if qkv.dtype != _BF16:
+        return f"dtype {qkv.dtype} (native attention is bf16)"
+    if qkv.dim() != 3 or qkv.shape[2] != 3 * heads * 64:
+        return f"head_dim {qkv.shape[-1] // (3 * heads)} (native attention is head_dim 64)"
+    if qkv.shape[1] > 256:
+        return f"sequence length {qkv.shape[1]} > 256"
+    return None
+
+
+def attention_fwd(qkv, heads: int):
+    """packed qkv [B, S, 3*H*64] -> (out [B, S, H*64], lse [B, H, S]); softmax scale 1/sqrt(64)"""
+    return _C.attention_fwd(qkv.contiguous(), heads)
+
+
+def attention_bwd(dout, qkv, out, lse, heads: int):
+    return _C.attention_bwd(dout.contiguous(), qkv, out, lse, heads)
+
+
 # ---------------------------------------------------------------- layernorm
 def layernorm_unsupported_reason(x):
     if x.dtype != _BF16:

@@ -116,6 +116,40 @@ def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, psums, count, relu: bool, want_d
     return dx.to(x.dtype), dres, sums
 
 
+# ------------------------------------------------------------ attention ----
+def _split_heads(qkv, heads):
+    b, s, w = qkv.shape
+    hd = w // (3 * heads)
+    t = qkv.view(b, s, 3, heads, hd).permute(2, 0, 3, 1, 4)  # [3, b, h, s, hd]
+    return t[0], t[1], t[2], hd
+
+
+def attention_fwd(qkv, heads: int):
+    q, k, v, hd = _split_heads(qkv, heads)
+    scores = torch.matmul(q.float() * (hd ** -0.5), k.float().transpose(-1, -2))
+    lse = torch.logsumexp(scores, dim=-1)
+    p = torch.exp(scores - lse[..., None])
+    out = torch.matmul(p, v.float()).transpose(1, 2).reshape(qkv.shape[0], qkv.shape[1], heads * hd)
+    return out.to(qkv.dtype), lse
+
+
+def attention_bwd(dout, qkv, out, lse, heads: int):
+    q, k, v, hd = _split_heads(qkv, heads)
+    b, s, _ = qkv.shape
+    scale = hd ** -0.5
+    qf, kf, vf = q.float(), k.float(), v.float()
+    do = dout.float().view(b, s, heads, hd).transpose(1, 2)
+    o = out.float().view(b, s, heads, hd).transpose(1, 2)
+    p = torch.exp(torch.matmul(qf * scale, kf.transpose(-1, -2)) - lse[..., None])
+    dv = torch.matmul(p.transpose(-1, -2), do)
+    dp = torch.matmul(do, vf.transpose(-1, -2))
+    ds = p * (dp - (do * o).sum(-1, keepdim=True))
+    dq = torch.matmul(ds, kf) * scale
+    dk = torch.matmul(ds.transpose(-1, -2), qf) * scale
+    dqkv = torch.stack([dq, dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(b, s, 3 * heads * hd)
+    return dqkv.to(qkv.dtype)
+
+
 # ------------------------------------------------------------ layernorm ----
 def layernorm_fwd(x, gamma, beta, eps: float):
     xf = x.float()

@@ -61,6 +61,13 @@ def test_conv_kernels_fwd_dgrad_wgrad(kc, case):
     _assert_all_ok(kc, n)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 1), (3, 197, 2), (2, 50, 3), (1, 256, 2), (2, 17, 1), (8, 197, 12)])
+def test_attention_kernels(kc, shape):
+    n = len(kc.RESULTS)
+    kc.check_attention(*shape, False)
+    _assert_all_ok(kc, n)
+
+
 @pytest.mark.parametrize("shape", [(5, 768), (592, 256), (1030, 1024), (8 * 197, 768)])
 def test_layernorm_kernels(kc, shape):
     n = len(kc.RESULTS)

@@ -326,3 +326,22 @@ def test_layer_norm_function_matches_torch_autograd():
     yr.backward(dy)
     for a, r in zip(got, [yr.detach(), x.grad, w.grad, b.grad]):
         assert torch.allclose(a, r, rtol=1e-4, atol=1e-5)
+
+
+def test_attention_function_matches_torch_autograd():
+    """The oracle's hand-written attention backward (what the HIP kernel is checked against) vs autograd."""
+    from pytorch_distributed_training_amd.nn.functional import attention
+
+    torch.manual_seed(0)
+    b, s, h, hd = 2, 5, 3, 8
+    qkv = torch.randn(b, s, 3 * h * hd, requires_grad=True)
+    dy = torch.randn(b, s, h * hd)
+    out = attention(qkv, h)
+    out.backward(dy)
+    g = qkv.grad.clone()
+    qkv.grad = None
+    q, k, v = qkv.view(b, s, 3, h, hd).permute(2, 0, 3, 1, 4)
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, s, h * hd)
+    ref.backward(dy)
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(g, qkv.grad, rtol=1e-4, atol=1e-5)
