@@ -142,8 +142,33 @@ def check_conv(args, time_it):
             extra.update({"us": round(us, 1), "us_miopen": round(us_lib, 1), "TF": round(fl / us / 1e6, 1)})
         record(f"conv_wgrad {tag}", e < 2e-2, e, extra)
 
+    def dgrad_bnr():
+        """stride-1 dgrad with the BN-backward reduction of the producing BN+ReLU fused into the epilogue"""
+        if s != 1:
+            return
+        dy = nhwc(B, N, H, W) if k == 1 or p * 2 + 1 == k else None
+        if dy is None:
+            return
+        xb = nhwc(B, C, H, W) * 2 + 0.3          # the BN's input
+        xb = xb.contiguous(memory_format=torch.channels_last)
+        gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1
+        mean, invstd = reference.bn_finalize(reference.bn_stats(xb), float(B * H * W), 1e-5)
+        z, act = native.bn_apply_act(xb, mean, invstd, gamma, beta, None, True)
+        add = nhwc(B, C, H, W)
+        dx, ps = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add, (xb, act, mean, invstd))
+        dx2 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add)
+        ps2 = native.bn_bwd_reduce(dx2, act, xb, mean, invstd, True)
+        e = max(rel_err(dx, dx2), rel_err(native.bn_sum_partials(ps), native.bn_sum_partials(ps2)))
+        extra = {}
+        if time_it:
+            extra["us_fused"] = round(timeit(lambda: native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add, (xb, act, mean, invstd))), 1)
+            extra["us_dgrad"] = round(timeit(lambda: native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add)), 1)
+            extra["us_reduce"] = round(timeit(lambda: native.bn_bwd_reduce(dx2, act, xb, mean, invstd, True)), 1)
+        record(f"conv_dgrad+bn_reduce {tag}", e < 2e-3, e, extra)
+
     run_case(f"conv_fwd   {tag}", fwd)
     run_case(f"conv_dgrad {tag}", dgrad)
+    run_case(f"conv_dgrad+bnr {tag}", dgrad_bnr)
     run_case(f"conv_wgrad {tag}", wgrad)
 
 

@@ -112,9 +112,15 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
 }
 
 // wt: [Cin][KH*KW][Cout] bf16 contiguous (transpose_weight(w))
-Tensor conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_shape, int64_t KH, int64_t KW,
-                    int64_t stride, int64_t pad, const c10::optional<Tensor>& addend) {
+// bn_*: when given (stride 1 only), dx is the gradient w.r.t. the OUTPUT of a BN+ReLU with input bn_x / activity
+// mask bn_mask / statistics bn_mean, bn_invstd, and the second result holds the BN-backward partial sums
+// [P<=32, 2, Cin] computed in the epilogue (what bn_bwd_reduce would return for this dx).
+std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_shape, int64_t KH,
+                                        int64_t KW, int64_t stride, int64_t pad, const c10::optional<Tensor>& addend,
+                                        const c10::optional<Tensor>& bn_x, const c10::optional<Tensor>& bn_mask,
+                                        const c10::optional<Tensor>& bn_mean, const c10::optional<Tensor>& bn_invstd) {
     check_nhwc_bf16(dy, "dy");
+    const bool bnr = bn_x.has_value() && bn_x->defined();
     const void* addend_ptr = nullptr;
     if (addend.has_value() && addend->defined()) {
         check_nhwc_bf16(*addend, "addend");
@@ -155,9 +161,30 @@ Tensor conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_s
                 g.dh[t] = (int8_t)(pad - r); g.dw[t] = (int8_t)(pad - q); g.wslot[t] = (int8_t)t;
             }
         g.addend = addend_ptr;
-        launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, nullptr, s);
-        return dx;
+        Tensor psums, slab;
+        float* slab_ptr = nullptr;
+        int m_tiles = 0;
+        if (bnr) {
+            check_nhwc_bf16(*bn_x, "bn_x");
+            TORCH_CHECK(bn_x->sizes().vec() == x_shape, "bn_x must have the shape of dx");
+            TORCH_CHECK(bn_mask.has_value() && bn_mask->is_cuda() && bn_mask->scalar_type() == at::kByte &&
+                            bn_mask->is_contiguous() && bn_mask->numel() == B * H * W * (C / 8),
+                        "bn_mask: expected contiguous uint8 [B*H*W, C/8]");
+            TORCH_CHECK(bn_mean.has_value() && bn_invstd.has_value(), "bn_mean / bn_invstd missing");
+            check_vec_f32(*bn_mean, C, "bn_mean"); check_vec_f32(*bn_invstd, C, "bn_invstd");
+            g.bnr_x = bn_x->data_ptr();
+            g.bnr_mask = bn_mask->data_ptr<uint8_t>();
+            g.bnr_mean = bn_mean->data_ptr<float>();
+            g.bnr_invstd = bn_invstd->data_ptr<float>();
+            m_tiles = conv_igemm_m_tiles(g, nullptr);
+            slab = at::empty({m_tiles, 2 * C}, dy.options().dtype(at::kFloat));
+            slab_ptr = slab.data_ptr<float>();
+        }
+        launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, slab_ptr, s);
+        if (bnr) psums = shrink_rows(slab, m_tiles, 2 * C, kReduceChunks).view({-1, 2, C});
+        return {dx, psums};
     }
+    TORCH_CHECK(!bnr, "the fused BN-backward reduction is implemented for stride-1 data gradients");
     // stride 2: one launch per output parity class; a class without taps stays zero
     bool need_zero = false;
     std::vector<ConvGeom> launches;
@@ -186,7 +213,7 @@ Tensor conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_s
     if (need_zero) dx.zero_();
     TORCH_CHECK((long)dx.numel() * 2 < (1L << 31), "dx exceeds 2 GiB");
     for (const auto& g : launches) launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, nullptr, s);
-    return dx;
+    return {dx, Tensor()};
 }
 
 bool wgrad_win_enabled() {
@@ -821,7 +848,9 @@ void multi_flatten_tensors(std::vector<at::Tensor>& srcs, std::vector<at::Tensor
 void bind_ops(pybind11::module& m) {
     m.def("conv2d_fwd", &conv2d_fwd);
     m.def("conv2d_dgrad", &conv2d_dgrad, pybind11::arg("dy"), pybind11::arg("wt"), pybind11::arg("x_shape"), pybind11::arg("kh"),
-          pybind11::arg("kw"), pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("addend") = pybind11::none());
+          pybind11::arg("kw"), pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("addend") = pybind11::none(),
+          pybind11::arg("bn_x") = pybind11::none(), pybind11::arg("bn_mask") = pybind11::none(),
+          pybind11::arg("bn_mean") = pybind11::none(), pybind11::arg("bn_invstd") = pybind11::none());
     m.def("conv2d_wgrad", &conv2d_wgrad);
     m.def("conv_stem_fwd", &conv_stem_fwd);
     m.def("stem_pack_x", &stem_pack_x);

@@ -182,6 +182,30 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     char* Os = smem;
     float* Ss = reinterpret_cast<float*>(smem + BM * OPITCH);
     const bool odd = lane & 1;
+    const bool bnr = g.bnr_x != nullptr;               // fused BN-backward reduction (data-gradient launches)
+    const bool fwd_stats = stats_slab != nullptr && !bnr;
+    // bnr: fetch this thread's rows of the BN input and mask NOW, so their latency hides behind the LDS staging of
+    // the output tile instead of sitting in the store loop
+    constexpr int CH = BN / 8;          // 16-B chunks per output row
+    constexpr int ORPP = 256 / CH;      // output rows per pass
+    constexpr int NPASS = BM / ORPP;
+    const int orow = tid / CH, och = tid % CH;
+    const int ncol = tile_n * BN + och * 8;
+    bf16x8 bx[NPASS];
+    unsigned bbits[NPASS];
+    if (bnr) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const long m = (long)tile_m * BM + p * ORPP + orow;  // bnr launches are dense stride-1: pixel == m
+            bbits[p] = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bx[p][k] = (bf16)0.f;
+            if (m < M && ncol < g.N) {
+                bx[p] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.bnr_x) + m * g.N + ncol);
+                bbits[p] = g.bnr_mask[(m * g.N + ncol) >> 3];
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         float csum = 0.f, csq = 0.f;
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                 *reinterpret_cast<uint32_t*>(Os + row * OPITCH + c2 * 2) = packed;
             }
         }
-        if (stats_slab != nullptr) {
+        if (fwd_stats) {
             csum += __shfl_xor(csum, 32, 64);
             csq += __shfl_xor(csq, 32, 64);
             if (lane < 32) {
@@ -215,7 +239,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     }
     __syncthreads();
 
-    if (stats_slab != nullptr && tid < BN) {
+    if (fwd_stats && tid < BN) {
         const int n = tile_n * BN + tid;
         if (n < g.N) {
             float s0 = 0.f, s1 = 0.f;
@@ -230,13 +254,19 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
         }
     }
 
-    constexpr int CH = BN / 8;          // 16-B chunks per output row
-    constexpr int ORPP = 256 / CH;      // output rows per pass
-    const int orow = tid / CH, och = tid % CH;
     const bool dense = (g.os == 1 && g.nOH == g.Hout && g.nOW == g.Wout);
-    const int ncol = tile_n * BN + och * 8;
+    float r0[8], r1[8], mu[8], is[8];  // bnr: this thread's 8 channels, summed over the rows it stores
+    if (bnr) {
 #pragma unroll
-    for (int p = 0; p < BM / ORPP; ++p) {
+        for (int k = 0; k < 8; ++k) {
+            r0[k] = 0.f;
+            r1[k] = 0.f;
+            mu[k] = ncol < g.N ? g.bnr_mean[ncol + k] : 0.f;
+            is[k] = ncol < g.N ? g.bnr_invstd[ncol + k] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
         const int row = p * ORPP + orow;
         const long m = (long)tile_m * BM + row;
         if (m < M && ncol < g.N) {
@@ -256,7 +286,50 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)a[k]);
             }
+            if (bnr) {
+                const bf16x8 xv = bx[p];
+                const unsigned bits = bbits[p];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float gg = ((bits >> k) & 1u) ? (float)v[k] : 0.f;
+                    r0[k] += gg;
+                    r1[k] += gg * ((float)xv[k] - mu[k]) * is[k];
+                }
+            }
             *reinterpret_cast<bf16x8*>(y + pix * g.N + ncol) = v;
+        }
+    }
+    if (bnr) {
+        // lanes och, och + CH, ... of a wave own the same 8 channels: butterfly over them, then the 4 waves via LDS
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int o = CH; o < 64; o <<= 1) {
+                r0[k] += __shfl_xor(r0[k], o, 64);
+                r1[k] += __shfl_xor(r1[k], o, 64);
+            }
+        }
+        if (lane < CH) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                Ss[(wave * BN + och * 8 + k) * 2 + 0] = r0[k];
+                Ss[(wave * BN + och * 8 + k) * 2 + 1] = r1[k];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int n = tile_n * BN + tid;
+            if (n < g.N) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s0 += Ss[(k * BN + tid) * 2 + 0];
+                    s1 += Ss[(k * BN + tid) * 2 + 1];
+                }
+                float* dst = stats_slab + (long)tile_m * 2 * g.N;
+                dst[n] = s0;
+                dst[g.N + n] = s1;
+            }
         }
     }
 }
@@ -266,7 +339,7 @@ void launch_cfg(const void* x, const void* w, void* y, const ConvGeom& g, float*
     const long M = (long)g.B * g.nOH * g.nOW;
     const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = (g.N + BN - 1) / BN;
     size_t lds = (size_t)2 * (BM + BN) * BK * 2;                      // double-buffered operand tiles
-    const size_t epi = (size_t)BM * BN * 2 + (size_t)WM * BN * 2 * 4;  // staged output tile + stats scratch
+    const size_t epi = (size_t)BM * BN * 2 + (size_t)4 * BN * 2 * 4;  // staged output tile + stats scratch (4 waves)
     if (lds < epi) lds = epi;
     const uint32_t xb = (uint32_t)((long)g.B * g.Hin * g.Win * (g.pix_elems ? g.pix_elems : g.C) * 2);
     const uint32_t wb = (uint32_t)((long)g.N * g.wtaps * g.C * 2);

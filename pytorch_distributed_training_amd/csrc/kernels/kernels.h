@@ -119,6 +119,15 @@ struct ConvGeom {
     // elements per input pixel in memory; 0 = C (dense NHWC).  The packed stem runs with C = 32 (one filter
     // row: 8 kw slots x 4 channels, contiguous in memory) over pixels of 4 elements.
     int pix_elems;
+    // BatchNorm-backward reduction fused into a data-gradient epilogue: when bnr_x != nullptr the output of this
+    // launch is the gradient dz w.r.t. the OUTPUT of a BN+ReLU whose input was bnr_x (same shape as the output)
+    // and whose 1-bit activity mask is bnr_mask; the epilogue then also writes, per m-tile, the partial rows
+    // [sum(dz*m), sum(dz*m*xhat)] to the slab argument, so the standalone bn_bwd_reduce pass (a full re-read of
+    // dz and x) is not needed.
+    const void* bnr_x;
+    const uint8_t* bnr_mask;
+    const float* bnr_mean;
+    const float* bnr_invstd;
 };
 // y = conv(x, w); when stats_slab != nullptr also writes per-(m-tile) partial [sum, sum_sq] rows
 // stats_slab[m_tile][2][N] computed from the bf16-rounded outputs.

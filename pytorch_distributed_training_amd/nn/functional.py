@@ -52,13 +52,18 @@ class _Conv2dFn(torch.autograd.Function):
     def forward(ctx, x, w, w_lp, stride, padding, want_stats, with_skip):
         wk = w_lp if w_lp is not None else w
         be = backend_for(x)
-        x = _cl(x)
         if be is not reference:
             why = be.conv_unsupported_reason(x, wk, stride, padding)
             if why is not None:
                 _note_fallback("conv2d", why)
                 be = reference
                 want_stats = False  # the BN node's native one-pass bn_stats beats torch reductions over y
+        # the BN+ReLU that produced x (if any) lets this node's data-gradient kernel do its backward reduction
+        sink = getattr(x, "_pdt_bn_sink", None)
+        x = _cl(x)
+        if sink is not None and not (be is not reference and stride == 1 and sink.usable_for(x)):
+            sink = None
+        ctx.bn_sink = sink
         y, stats, saved = be.conv2d_fwd(x, wk, stride, padding, want_stats, True)
         ctx.set_materialize_grads(False)  # no zero-filled gradient for the (non-differentiable) stats output
         ctx.save_for_backward(saved, wk)  # `saved` is x, or the packed image of the native 3-channel stem
@@ -76,7 +81,13 @@ class _Conv2dFn(torch.autograd.Function):
             return dskip, None, None, None, None, None, None
         dy = _cl(dy)
         if ctx.needs_input_grad[0]:
-            dx = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, None if dskip is None else _cl(dskip))
+            sink = ctx.bn_sink
+            dskip = None if dskip is None else _cl(dskip)
+            if sink is not None:
+                dx, psums = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, dskip, sink.operands())
+                sink.fulfil(dx, psums)
+            else:
+                dx = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, dskip)
         if ctx.needs_input_grad[1]:
             dw = be.conv2d_wgrad(dy, x, w_shape, stride, padding)
             if dw.dtype != w_dtype:
@@ -115,9 +126,42 @@ def _sync_world(cfg: BNConfig) -> int:
     return tdist.get_world_size(cfg.group)
 
 
+class _BNSink:
+    """Hand-over between a BN+ReLU node and the conv node that consumes its output.  The conv's data-gradient
+    kernel produces exactly the tensor this BN's backward receives as ``dz``; given the BN's saved operands it can
+    reduce ``[sum(dz*m), sum(dz*m*xhat)]`` in its epilogue while the tile is still in registers, and the BN backward
+    then skips its own reduction pass (one full read of dz and x per layer).  The BN only trusts the result when
+    the gradient it receives is that very tensor."""
+
+    __slots__ = ("x", "mask", "mean", "invstd", "psums", "dz_ptr", "dz_version")
+
+    def __init__(self):
+        self.x = self.mask = self.mean = self.invstd = self.psums = None
+        self.dz_ptr = self.dz_version = None
+
+    def arm(self, x, mask, mean, invstd):
+        self.x, self.mask, self.mean, self.invstd = x, mask, mean, invstd
+
+    def usable_for(self, z) -> bool:
+        return self.x is not None and self.mask is not None and tuple(z.shape) == tuple(self.x.shape)
+
+    def operands(self):
+        return (self.x, self.mask, self.mean, self.invstd)
+
+    def fulfil(self, dz, psums) -> None:
+        self.psums, self.dz_ptr, self.dz_version = psums, dz.data_ptr(), dz._version
+
+    def take(self, dz):
+        """The fused partial sums if ``dz`` is the tensor they were computed from, else None."""
+        ps = self.psums
+        ok = ps is not None and dz.data_ptr() == self.dz_ptr and dz._version == self.dz_version
+        self.x = self.mask = self.mean = self.invstd = self.psums = None  # drop the references either way
+        return ps if ok else None
+
+
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, stats, cfg: BNConfig, relu: bool):
+    def forward(ctx, x, gamma, beta, residual, stats, cfg: BNConfig, relu: bool, sink=None):
         be = backend_for(x)
         x = _cl(x)
         if residual is not None:
@@ -156,6 +200,10 @@ class _BNActFn(torch.autograd.Function):
         g32 = gamma.float() if gamma is not None else torch.ones(c, device=x.device)
         b32 = beta.float() if beta is not None else torch.zeros(c, device=x.device)
         z, act = be.bn_apply_act(x, mean, invstd, g32, b32, residual, relu)
+        ctx.sink = None
+        if sink is not None and relu and be is not reference and act is not None and act.dtype == torch.uint8:
+            sink.arm(x, act, mean, invstd)
+            ctx.sink = sink
         ctx.save_for_backward(x, act if relu else None, mean, invstd, g32, count_t)
         ctx.cfg = (be, cfg, relu, world, count, residual is not None,
                    None if gamma is None else gamma.dtype, None if beta is None else beta.dtype)
@@ -165,8 +213,10 @@ class _BNActFn(torch.autograd.Function):
     def backward(ctx, dz):
         x, z, mean, invstd, g32, count_t = ctx.saved_tensors
         be, cfg, relu, world, count, has_res, gdt, bdt = ctx.cfg
+        psums = ctx.sink.take(dz) if ctx.sink is not None else None  # reduced by the consumer conv's dgrad epilogue
         dz = _cl(dz)
-        psums = be.bn_bwd_reduce(dz, z, x, mean, invstd, relu)  # local partial rows [P, 2, C]
+        if psums is None:
+            psums = be.bn_bwd_reduce(dz, z, x, mean, invstd, relu)  # local partial rows [P, 2, C]
         want_dres = has_res and ctx.needs_input_grad[3]
         if cfg.training and world > 1:
             # the affine grads stay local (DDP averages them); the sums that feed grad_input are global
@@ -185,10 +235,19 @@ class _BNActFn(torch.autograd.Function):
         dbeta = sums[0].to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
         if not ctx.needs_input_grad[0]:
             dx = None
-        return dx, dgamma, dbeta, dres, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None
+
+
+_FUSE_BN_REDUCE = os.environ.get("PDT_FUSE_BN_REDUCE", "1") != "0"
 
 
 def bn_act(x, gamma, beta, cfg: BNConfig, residual=None, relu: bool = False, stats=None):
+    if relu and _FUSE_BN_REDUCE and x.is_cuda and torch.is_grad_enabled():
+        sink = _BNSink()
+        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, True, sink)
+        if sink.x is not None:
+            z._pdt_bn_sink = sink  # picked up by the conv node that consumes z
+        return z
     return _BNActFn.apply(x, gamma, beta, residual, stats, cfg, bool(relu))
 
 

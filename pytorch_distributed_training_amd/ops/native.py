@@ -109,12 +109,16 @@ def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False, return
     return (y, stats, saved) if return_saved else (y, stats)
 
 
-def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None):
+def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None, bn_sink=None):
+    """``bn_sink = (x, mask, mean, invstd)`` of the BN+ReLU that produced this conv's input: the kernel epilogue
+    then also reduces that BN's backward sums and the call returns ``(dx, psums)`` (stride 1 only)."""
     kh, kw = w.shape[2], w.shape[3]
     wt = _transposed(w)  # [Cin][taps][Cout]: K-contiguous operand for the dgrad GEMM
+    if bn_sink is not None:
+        return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend, *bn_sink)
     if addend is not None and stride != 1:
-        return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, None) + addend
-    return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend)
+        return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, None)[0] + addend
+    return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend)[0]
 
 
 def conv2d_wgrad(dy, x, w_shape, stride: int, padding: int):
