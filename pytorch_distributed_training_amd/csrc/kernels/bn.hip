@@ -17,6 +17,7 @@ namespace pdt {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kUnroll = 4;  // rows per thread and trip in the streaming kernels
 
 struct Map {
     int G;       // channel groups of 8 per row (C/8), power of two <= 256
@@ -151,8 +152,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ 
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta) {
     const Map m = make_map(C);
-    long r0, r1;
-    block_rows(M, r0, r1);
     float a[8], b[8];
     {
         float mu[8], is[8], ga[8], be[8];
@@ -166,27 +165,42 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ 
             b[k] = be[k] - mu[k] * a[k];
         }
     }
-    for (long r = r0 + m.rl; r < r1; r += m.R) {
-        const long off = r * C + m.cg * 8;
-        const bf16x8 v = ld8(x + off);
-        float o[8];
+    // grid-stride rows (the whole grid walks memory front to back), kUnroll rows per trip with all their loads
+    // issued before the first use: enough bytes in flight per CU to cover HBM latency
+    const long S = (long)gridDim.x * m.R;
+    for (long rb = (long)blockIdx.x * m.R + m.rl; rb < M; rb += kUnroll * S) {
+        bf16x8 v[kUnroll], rv[kUnroll];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = (float)v[k] * a[k] + b[k];
-        if (RES) {
-            const bf16x8 rv = ld8(res + off);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] += (float)rv[k];
-        }
-        if (RELU) {
-            unsigned bits = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                bits |= (o[k] > 0.f ? 1u : 0u) << k;
-                o[k] = fmaxf(o[k], 0.f);
+        for (int u = 0; u < kUnroll; ++u) {
+            const long r = rb + u * S;
+            if (r < M) {
+                v[u] = ld8(x + r * C + m.cg * 8);
+                if (RES) rv[u] = ld8(res + r * C + m.cg * 8);
             }
-            mask[r * m.G + m.cg] = (uint8_t)bits;
         }
-        st8(z + off, o);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const long r = rb + u * S;
+            if (r >= M) break;
+            const long off = r * C + m.cg * 8;
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (float)v[u][k] * a[k] + b[k];
+            if (RES) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] += (float)rv[u][k];
+            }
+            if (RELU) {
+                unsigned bits = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    bits |= (o[k] > 0.f ? 1u : 0u) << k;
+                    o[k] = fmaxf(o[k], 0.f);
+                }
+                mask[r * m.G + m.cg] = (uint8_t)bits;
+            }
+            st8(z + off, o);
+        }
     }
 }
 
@@ -197,24 +211,34 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const bf16* __restri
                                                             const float* __restrict__ invstd,
                                                             float* __restrict__ slab) {
     const Map m = make_map(C);
-    long r0, r1;
-    block_rows(M, r0, r1);
     float mu[8], is[8];
     ld8f(mean + m.cg * 8, mu);
     ld8f(invstd + m.cg * 8, is);
     float s0[8] = {0}, s1[8] = {0};
-    for (long r = r0 + m.rl; r < r1; r += m.R) {
-        const long off = r * C + m.cg * 8;
-        const bf16x8 g = ld8(dz + off);
-        const bf16x8 xv = ld8(x + off);
-        unsigned bits = 0xffu;
-        if (RELU) bits = mask[r * m.G + m.cg];
+    const long S = (long)gridDim.x * m.R;
+    for (long rb = (long)blockIdx.x * m.R + m.rl; rb < M; rb += kUnroll * S) {
+        bf16x8 g[kUnroll], xv[kUnroll];
+        unsigned bits[kUnroll];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float gg = (float)g[k];
-            if (RELU) gg = ((bits >> k) & 1u) ? gg : 0.f;
-            s0[k] += gg;
-            s1[k] += gg * ((float)xv[k] - mu[k]) * is[k];
+        for (int u = 0; u < kUnroll; ++u) {
+            const long r = rb + u * S;
+            bits[u] = 0xffu;
+            if (r < M) {
+                g[u] = ld8(dz + r * C + m.cg * 8);
+                xv[u] = ld8(x + r * C + m.cg * 8);
+                if (RELU) bits[u] = mask[r * m.G + m.cg];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (rb + u * S >= M) break;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float gg = (float)g[u][k];
+                if (RELU) gg = ((bits[u] >> k) & 1u) ? gg : 0.f;
+                s0[k] += gg;
+                s1[k] += gg * ((float)xv[u][k] - mu[k]) * is[k];
+            }
         }
     }
     block_reduce_store(m, C, s0, s1, slab);
@@ -232,8 +256,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
                                                            float* __restrict__ sums_out, float count,
                                                            const float* __restrict__ count_dev) {
     const Map m = make_map(C);
-    long r0, r1;
-    block_rows(M, r0, r1);
     const float invn = 1.f / (count_dev ? count_dev[0] : count);
     float k1[8], k2[8], k3[8];
     {
@@ -268,22 +290,36 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
             k3[k] = g_is * (c2 * is[k] * mu[k] - c1);
         }
     }
-    for (long r = r0 + m.rl; r < r1; r += m.R) {
-        const long off = r * C + m.cg * 8;
-        const bf16x8 g = ld8(dz + off);
-        const bf16x8 xv = ld8(x + off);
-        unsigned bits = 0xffu;
-        if (RELU) bits = mask[r * m.G + m.cg];
-        float o[8], gm[8];
+    const long S = (long)gridDim.x * m.R;
+    for (long rb = (long)blockIdx.x * m.R + m.rl; rb < M; rb += kUnroll * S) {
+        bf16x8 g[kUnroll], xv[kUnroll];
+        unsigned bits[kUnroll];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float gg = (float)g[k];
-            if (RELU) gg = ((bits >> k) & 1u) ? gg : 0.f;
-            gm[k] = gg;
-            o[k] = k1[k] * gg + k2[k] * (float)xv[k] + k3[k];
+        for (int u = 0; u < kUnroll; ++u) {
+            const long r = rb + u * S;
+            bits[u] = 0xffu;
+            if (r < M) {
+                g[u] = ld8(dz + r * C + m.cg * 8);
+                xv[u] = ld8(x + r * C + m.cg * 8);
+                if (RELU) bits[u] = mask[r * m.G + m.cg];
+            }
         }
-        st8(dx + off, o);
-        if (DRES) st8(dres + off, gm);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const long r = rb + u * S;
+            if (r >= M) break;
+            const long off = r * C + m.cg * 8;
+            float o[8], gm[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float gg = (float)g[u][k];
+                if (RELU) gg = ((bits[u] >> k) & 1u) ? gg : 0.f;
+                gm[k] = gg;
+                o[k] = k1[k] * gg + k2[k] * (float)xv[u][k] + k3[k];
+            }
+            st8(dx + off, o);
+            if (DRES) st8(dres + off, gm);
+        }
     }
 }
 
