@@ -41,7 +41,8 @@ def main(argv=None) -> int:
     ap.add_argument("--warmup", type=int, default=10)
     # per-GPU batch sized for 288 GB HBM3E: at 1024 the step holds ~100 GB of bf16 activations, every conv launch
     # has >10 rounds of tiles per CU (no tail effect) and the gradient all-reduce is <2 % of the step
-    ap.add_argument("--batch_size", type=int, default=1024, help="per-GPU batch")
+    ap.add_argument("--batch_size", type=int, default=1024,
+                    help="per-GPU batch; 0 = size it from the memory model (utils/memory.py)")
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--image_size", type=int, default=224)
     ap.add_argument("--num_classes", type=int, default=1000)
@@ -73,6 +74,12 @@ def main(argv=None) -> int:
         lr=0.1 if args.optimizer == "sgd" else 1e-3, momentum=0.9, weight_decay=1e-4 if args.optimizer == "sgd" else 0.0,
         sync_bn=args.sync_bn, bucket_cap_mb=args.bucket_cap_mb, reducer=args.reducer, seed=0, graph=args.graph,
         image_size=args.image_size))
+    batch_model = None
+    if args.batch_size <= 0:
+        from pytorch_distributed_training_amd.utils.memory import suggest_batch
+
+        batch_model = suggest_batch(engine, (3, args.image_size, args.image_size), args.num_classes)
+        args.batch_size = batch_model["batch"]
     loader = SyntheticDeviceLoader(args.batch_size, (3, args.image_size, args.image_size), args.num_classes,
                                    device=env.device, dtype=torch.float32, ring=2, seed=env.rank)
     it = iter(loader)
@@ -127,7 +134,7 @@ def main(argv=None) -> int:
                 "optimizer": args.optimizer, "sync_bn": bool(args.sync_bn), "reducer": engine.net.reducer_kind,
                 "backend": env.backend, "baseline_images_per_sec": round(base, 1),
                 "library_fallbacks": dict(pF.fallback_counts), "final_loss": final_loss,
-                "hip_graph": bool(engine._graph is not None), "bucket_autotune": engine.net.bucket_autotune,
+                "hip_graph": bool(engine._graph is not None), "batch_model": batch_model, "bucket_autotune": engine.net.bucket_autotune,
             },
         }
         print(json.dumps(out), flush=True)

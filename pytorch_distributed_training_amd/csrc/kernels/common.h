@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fastdiv.h"
+
 namespace pdt {
 
 typedef __bf16 bf16;
@@ -42,22 +44,6 @@ constexpr uint32_t kOOB = 0x80000000u;  // > any legal byte offset (tensors are 
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// division by a launch-constant via multiply-high (exact for n < 2^31): the implicit-GEMM index math
-// (pixel -> image / row / column) runs on the VALU next to the MFMAs and must not cost a v_div sequence
-struct FastDiv {
-    uint32_t mlo, shift, d;
-};
-inline FastDiv make_fastdiv(uint32_t d) {
-    FastDiv f;
-    f.d = d;
-    uint32_t L = 0;
-    while ((1u << L) < d) ++L;
-    const unsigned __int128 one = 1;
-    const unsigned __int128 magic = ((one << (32 + L)) + d - 1) / d;  // ceil(2^(32+L) / d), in [2^32, 2^33)
-    f.mlo = (uint32_t)(magic - (one << 32));
-    f.shift = L;
-    return f;
-}
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
     return (n + __umulhi(n, f.mlo)) >> f.shift;
 }

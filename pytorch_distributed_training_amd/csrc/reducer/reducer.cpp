@@ -11,35 +11,12 @@
 namespace pdt {
 
 namespace {
-constexpr int64_t kAlign = 128;  // elements; every slot stays 256/512-B aligned for 16 B/lane access
-int64_t pad(int64_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
-
 #define PDT_HIP(expr)                                                                \
     do {                                                                             \
         hipError_t _e = (expr);                                                      \
         TORCH_CHECK(_e == hipSuccess, "HIP error: ", hipGetErrorString(_e), " (" #expr ")"); \
     } while (0)
 }  // namespace
-
-std::vector<BucketPlan> plan_buckets(const std::vector<int64_t>& numels, const std::vector<int64_t>& order,
-                                     int64_t elem_size, int64_t cap_bytes, int64_t first_cap_bytes) {
-    std::vector<BucketPlan> out;
-    BucketPlan cur;
-    int64_t cap = first_cap_bytes > 0 ? first_cap_bytes : cap_bytes;
-    for (int64_t idx : order) {
-        const int64_t n = pad(numels[idx]);
-        if (!cur.params.empty() && (cur.numel + n) * elem_size > cap) {
-            out.push_back(std::move(cur));
-            cur = BucketPlan();
-            cap = cap_bytes;
-        }
-        cur.params.push_back(idx);
-        cur.offsets.push_back(cur.numel);
-        cur.numel += n;
-    }
-    if (!cur.params.empty()) out.push_back(std::move(cur));
-    return out;
-}
 
 Reducer::Reducer(std::vector<at::Tensor> params, std::vector<std::string> names, std::shared_ptr<RcclComm> rccl,
                  c10::intrusive_ptr<c10d::ProcessGroup> pg, int64_t world_size, int64_t cap_bytes,

@@ -25,16 +25,9 @@
 
 #include "../comm/rccl_comm.h"
 
+#include "bucket_plan.h"
+
 namespace pdt {
-
-struct BucketPlan {
-    std::vector<int64_t> params;   // parameter indices
-    std::vector<int64_t> offsets;  // element offsets in the flat buffer
-    int64_t numel = 0;             // padded size
-};
-
-std::vector<BucketPlan> plan_buckets(const std::vector<int64_t>& numels, const std::vector<int64_t>& order,
-                                     int64_t elem_size, int64_t cap_bytes, int64_t first_cap_bytes);
 
 class Reducer {
    public:

@@ -258,6 +258,18 @@ def test_hip_graph_step_matches_eager(opt):
     assert runs[1][-2] < runs[1][0] and runs[1][-1] < runs[1][1], runs
 
 
+def test_batch_sizing_model_resnet50():
+    """ResNet-50 at 224x224: ~100 MB of bf16 activations per image; the 2 GiB buffer-descriptor range of the widest
+    activation (stem output / packed stem input), not the 288 GB of HBM, is what bounds the per-GPU batch."""
+    from pytorch_distributed_training_amd.utils.memory import suggest_batch
+
+    eng = _engine(optimizer="sgd", lr=0.01, sync_bn=False)
+    m = suggest_batch(eng, (3, 224, 224), 1000, probe=8)
+    assert 60e6 < m["bytes_per_image"] < 200e6, m
+    assert m["by_memory"] > 1024 and 1024 <= m["by_tensor_range"] < 2048, m
+    assert m["batch"] == min(m["by_memory"], m["by_tensor_range"]) // 64 * 64, m
+
+
 def test_main_py_single_gpu_through_launcher(tmp_path):
     """SURVEY §7.3 exit criteria: loss decreases, byte-exact log header, profiler trace, strict checkpoint."""
     env = dict(os.environ, PYTHONPATH=ROOT)
