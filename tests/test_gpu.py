@@ -259,13 +259,13 @@ def test_hip_graph_step_matches_eager(opt):
 
 
 def test_batch_sizing_model_resnet50():
-    """ResNet-50 at 224x224: ~100 MB of bf16 activations per image; the 2 GiB buffer-descriptor range of the widest
+    """ResNet-50 at 224x224: ~40 MB of saved bf16 activations per image; the 2 GiB buffer-descriptor range of the widest
     activation (stem output / packed stem input), not the 288 GB of HBM, is what bounds the per-GPU batch."""
     from pytorch_distributed_training_amd.utils.memory import suggest_batch
 
     eng = _engine(optimizer="sgd", lr=0.01, sync_bn=False)
     m = suggest_batch(eng, (3, 224, 224), 1000, probe=8)
-    assert 60e6 < m["bytes_per_image"] < 200e6, m
+    assert 20e6 < m["bytes_per_image"] < 200e6, m
     assert m["by_memory"] > 1024 and 1024 <= m["by_tensor_range"] < 2048, m
     assert m["batch"] == min(m["by_memory"], m["by_tensor_range"]) // 64 * 64, m
 
