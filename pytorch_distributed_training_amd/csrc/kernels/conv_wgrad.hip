@@ -52,7 +52,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int krow0, int colba
 
 struct WgradArgs {
     int B, Hin, Win, C, Hout, Wout, N, KH, KW, stride, pad;
-    int n_tiles, c_tiles, splits;
+    int n_tiles, c_tiles, splits, xcd_remap;
     long M, m_per_split;
     FastDiv div_wo, div_howo;
     uint32_t x_bytes, dy_bytes;
@@ -76,7 +76,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const bf16* __restrict__ 
 
     // block -> (split, tap, n tile, c tile); tiles of one split are adjacent so the dY / X rows
     // they share are hot in L2
+    // XCD-aware bijective remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with
+    // its own L2), so give every XCD a CONTIGUOUS range of logical ids: the tiles and taps of one split then run
+    // on one XCD at about the same time and share their dY / X rows in that L2 instead of re-fetching them
     int bid = blockIdx.x;
+    if (a.xcd_remap) {
+        const int total = (int)gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int q = total >> 3, r = total & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
     const int tile_c = bid % a.c_tiles;
     bid /= a.c_tiles;
     const int tile_n = bid % a.n_tiles;
@@ -196,6 +204,10 @@ void launch_cfg(const void* dy, const void* x, float* slab, const WgradGeom& g, 
     a.n_tiles = (g.N + TNW - 1) / TNW;
     a.c_tiles = (g.C + TCW - 1) / TCW;
     a.splits = g.splits;
+    // measured on MI355X (bench/resnet50_roofline.py, B=256): sharing one XCD's L2 between the taps / tiles of a
+    // split wins where the layer is fetch-bound (64-128 channel 3x3: 260 -> 187 us, every 1x1: -5..-15 %) and
+    // loses where >= 36 MFMA-bound workgroups then hammer the same L2 lines at once (256-channel 3x3: 100 -> 123 us)
+    a.xcd_remap = !(g.KH * g.KW > 1 && g.C >= 256 && g.N >= 256);
     a.M = (long)g.B * g.Hout * g.Wout;
     long per = (a.M + g.splits - 1) / g.splits;
     per = (per + KM - 1) / KM * KM;
