@@ -17,6 +17,8 @@
 //  * LDS rows are 128/256 B with an XOR swizzle of the 16-B chunk chosen so that the four
 //    rows x 64 B that one half-wave touches in a transposed read fall on 64 distinct banks.
 //  * zero padding and the ragged end of a split come from the buffer range check.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -226,11 +228,16 @@ inline int tile_w(int dim) { return dim % 128 == 0 ? 128 : 64; }
 
 }  // namespace
 
+static const long kTargetBlocks = [] {
+    const char* e = std::getenv("PDT_WGRAD_BLOCKS");
+    return e ? std::atol(e) : 1024L;
+}();
+
 int conv_wgrad_splits(const WgradGeom& g) {
     const int tn = tile_w(g.N), tc = tile_w(g.C);
     const long tiles = (long)((g.N + tn - 1) / tn) * ((g.C + tc - 1) / tc) * g.KH * g.KW;
     const long M = (long)g.B * g.Hout * g.Wout;
-    long splits = (1024 + tiles - 1) / tiles;
+    long splits = (kTargetBlocks + tiles - 1) / tiles;
     const long max_splits = (M + 4 * KM - 1) / (4 * KM);  // at least 4 K-steps per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
