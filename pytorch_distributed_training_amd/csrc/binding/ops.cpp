@@ -96,7 +96,7 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
     for (int r = 0; r < KH; ++r)
         for (int s = 0; s < KW; ++s) {
             const int t = r * KW + s;
-            g.dh[t] = (int8_t)(r - pad); g.dw[t] = (int8_t)(s - pad); g.wslot[t] = (int8_t)t;
+            g.set_tap(t, r - (int)pad, s - (int)pad, t);
         }
     Tensor stats;
     float* slab_ptr = nullptr;
@@ -158,7 +158,7 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
         for (int r = 0; r < KH; ++r)
             for (int q = 0; q < KW; ++q) {
                 const int t = r * KW + q;
-                g.dh[t] = (int8_t)(pad - r); g.dw[t] = (int8_t)(pad - q); g.wslot[t] = (int8_t)t;
+                g.set_tap(t, (int)pad - r, (int)pad - q, t);
             }
         g.addend = addend_ptr;
         Tensor psums, slab;
@@ -198,9 +198,7 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
                 if (((ph + pad - r) % 2) != 0) continue;
                 for (int q = 0; q < KW; ++q) {
                     if (((pw + pad - q) % 2) != 0) continue;
-                    g.dh[nt] = (int8_t)((ph + pad - r) / 2);
-                    g.dw[nt] = (int8_t)((pw + pad - q) / 2);
-                    g.wslot[nt] = (int8_t)(r * KW + q);
+                    g.set_tap(nt, (int)((ph + pad - r) / 2), (int)((pw + pad - q) / 2), (int)(r * KW + q));
                     ++nt;
                 }
             }
@@ -280,7 +278,7 @@ std::tuple<Tensor, Tensor, Tensor> conv_stem_fwd(const Tensor& x, const Tensor& 
     std::memset(&g, 0, sizeof(g));
     g.B = B; g.Hin = Hp; g.Win = Wp; g.C = 32; g.pix_elems = 4; g.Hout = Ho; g.Wout = Wo; g.N = N;
     g.nOH = Ho; g.nOW = Wo; g.os = 1; g.is = 2; g.ntaps = 7; g.wtaps = 7;
-    for (int t = 0; t < 7; ++t) { g.dh[t] = (int8_t)t; g.dw[t] = 0; g.wslot[t] = (int8_t)t; }
+    for (int t = 0; t < 7; ++t) g.set_tap(t, t, 0, t);
     Tensor stats, slab;
     float* slab_ptr = nullptr;
     const int m_tiles = conv_igemm_m_tiles(g, nullptr);

@@ -40,6 +40,35 @@ __device__ __forceinline__ bf16x8 buffer_load_bf16x8(__amdgpu_buffer_rsrc_t rsrc
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
     return __builtin_bit_cast(bf16x8, v);
 }
+// ---- LDS-DMA (buffer_load_dwordx4 ... lds): 16 B per lane from a per-lane buffer offset straight into LDS at
+// wave-uniform address + 16 * lane, no VGPR destination.  Issued through inline asm on purpose: for the builtin
+// form the compiler cannot prove that a later ds_read does not alias the in-flight DMA and inserts its own
+// s_waitcnt vmcnt before every LDS read, which collapses a multi-stage ring to one stage in flight.  Hand-issued,
+// the DMA is invisible to the compiler's wait bookkeeping: the caller retires it with a counted
+// `s_waitcnt vmcnt(N)` followed by a barrier before any lane reads the data (verified by bench/micro/glds_probe.hip:
+// lane-linear placement, zeros for out-of-range lanes, destinations above 64 KiB).
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+__device__ __forceinline__ i32x4 make_rsrc_words(const void* base, uint32_t bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r[0] = (int)(uint32_t)a;
+    r[1] = (int)((uint32_t)(a >> 32) & 0xffffu);
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return (uint32_t)(unsigned long long)(lds_char_ptr)(const_cast<void*>(p));
+}
+__device__ __forceinline__ void lds_dma16(i32x4 rsrc, uint32_t byte_off, uint32_t lds_addr_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(byte_off), "s"(rsrc), "s"(lds_addr_uniform)
+        : "memory");
+}
+
 constexpr uint32_t kOOB = 0x80000000u;  // > any legal byte offset (tensors are < 2 GiB, checked on the host)
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

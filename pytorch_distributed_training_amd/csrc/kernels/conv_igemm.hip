@@ -39,7 +39,14 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * ROWB + ((chunk ^ ((row / RPB) & (CPR - 1))) << 4);
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int MINW>
+// NS == 0: operand tiles staged through registers, two LDS buffers (prefetch distance one K-step).
+// NS >= 3: LDS-DMA staging (buffer_load ... lds: no VGPR round trip, no ds_write) into a ring of NS stage
+//          buffers with NS-1 K-steps in flight: the loads of step k+NS-1 are issued before the MFMAs of step k
+//          and only a COUNTED s_waitcnt vmcnt retires step k+1 before the (raw) barrier, so global / L2 latency
+//          spans several K-steps instead of one.  The DMA writes LDS lane-linearly (wave base + 16 B * lane), so
+//          the XOR swizzle is applied on the SOURCE side: the lane that fills physical chunk p of a row fetches
+//          logical chunk p ^ swz(row).
+template <int BM, int BN, int WM, int WN, int BK, int MINW, int NS = 0>
 __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                        bf16* __restrict__ y, const ConvGeom g,
                                                        float* __restrict__ stats_slab, int m_tiles, int n_tiles,
@@ -102,7 +109,8 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     const int pix_elems = g.pix_elems ? g.pix_elems : g.C;  // memory elements per input pixel
     bf16x8 ra[PA], rb[PB];
     auto gload = [&](int t, int c0) {
-        const int dh = g.dh[t], dw = g.dw[t], ws = g.wslot[t];
+        const int tp = g.tap[__builtin_amdgcn_readfirstlane(t)];
+        const int dh = (int)(int8_t)(tp & 0xff), dw = (int)(int8_t)((tp >> 8) & 0xff), ws = (tp >> 16) & 0xff;
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int hi = rih[p] + dh, wi = riw[p] + dw;
@@ -135,28 +143,10 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
 
     const int cpt = g.C / BK;  // K-steps per tap
     const int nks = g.ntaps * cpt;
-    int t_next = 0, c_next = 0;
-    gload(0, 0);
-    lds_store(0);
-    __syncthreads();
-
     const int arow0 = wm * (BM / WM) + (lane & 31);
     const int brow0 = wn * (BN / WN) + (lane & 31);
     const int khalf = lane >> 5;
-
-    for (int ks = 0; ks < nks; ++ks) {
-        const int cur = ks & 1;
-        const bool more = ks + 1 < nks;
-        if (more) {
-            c_next += BK;
-            if (c_next == g.C) {
-                c_next = 0;
-                ++t_next;
-            }
-            gload(t_next, c_next);
-        }
-        const char* Ab = As + cur * A_BYTES;
-        const char* Bb = Bs + cur * B_BYTES;
+    auto mfma_step = [&](const char* Ab, const char* Bb) {
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             bf16x8 af[TM], bfr[TN];
@@ -172,8 +162,91 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (more) lds_store(cur ^ 1);
+    };
+
+    if constexpr (NS == 0) {
+        int t_next = 0, c_next = 0;
+        gload(0, 0);
+        lds_store(0);
         __syncthreads();
+        for (int ks = 0; ks < nks; ++ks) {
+            const int cur = ks & 1;
+            const bool more = ks + 1 < nks;
+            if (more) {
+                c_next += BK;
+                if (c_next == g.C) {
+                    c_next = 0;
+                    ++t_next;
+                }
+                gload(t_next, c_next);
+            }
+            mfma_step(As + cur * A_BYTES, Bs + cur * B_BYTES);
+            if (more) lds_store(cur ^ 1);
+            __syncthreads();
+        }
+    } else {
+        constexpr int STAGE = A_BYTES + B_BYTES;
+        constexpr int RPB = 256 / ROWB;
+        constexpr int LOADS = PA + PB;               // LDS-DMA instructions per thread and stage
+        constexpr int INFLIGHT = (NS - 2) * LOADS;   // what may still be outstanding once step k+1 must have landed
+        static_assert(INFLIGHT < 64, "vmcnt field");
+        const i32x4 rxw = make_rsrc_words(x, x_bytes), rww = make_rsrc_words(w, w_bytes);
+        const uint32_t lds0 = lds_address(smem) + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+        int ti = 0, ci = 0, issued = 0;
+        // issue the DMA loads of K-step `issued` into ring slot issued % NS
+        auto gissue = [&]() {
+            const uint32_t sa = lds0 + (uint32_t)((issued % NS) * STAGE);
+            // the tap index must stay in a scalar register: a vector index into the kernel-argument table would turn
+            // this read into a global load whose compiler-inserted vmcnt wait also drains the DMA ring
+            const int tp = g.tap[__builtin_amdgcn_readfirstlane(ti)];
+            const int dh = (int)(int8_t)(tp & 0xff), dw = (int)(int8_t)((tp >> 8) & 0xff), ws = (tp >> 16) & 0xff;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const int row = p * RPP + lrow;
+                const int lchunk = chunk ^ ((row / RPB) & (CPR - 1));
+                const int hi = rih[p] + dh, wi = riw[p] + dw;
+                const bool ok = (unsigned)hi < (unsigned)g.Hin && (unsigned)wi < (unsigned)g.Win;
+                const uint32_t off = (uint32_t)(((rowpix[p] + hi * g.Win + wi) * pix_elems + ci + lchunk * 8) * 2);
+                lds_dma16(rxw, ok ? off : kOOB, sa + (uint32_t)(p * RPP * ROWB));
+            }
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const int row = p * RPP + lrow;
+                const int lchunk = chunk ^ ((row / RPB) & (CPR - 1));
+                const uint32_t off = ((wrow[p] + (uint32_t)ws) * (uint32_t)g.C + (uint32_t)(ci + lchunk * 8)) * 2u;
+                lds_dma16(rww, wrow[p] != 0xffffffffu ? off : kOOB, sa + (uint32_t)(A_BYTES + p * RPP * ROWB));
+            }
+            ++issued;
+            ci += BK;
+            if (ci == g.C) {
+                ci = 0;
+                ++ti;
+            }
+        };
+        // retire the oldest stage still in flight: `ahead` = stages issued AFTER the one that must have landed
+        // (counted waits need literal operands; the tail of the K loop walks down the chain)
+        auto retire = [&](int ahead) {
+            if (NS >= 5 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LOADS) : "memory");
+            else if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        static_assert(NS <= 5 && 3 * LOADS < 64, "retire() chain / vmcnt field");
+        (void)INFLIGHT;
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nks) gissue();
+        retire(issued - 1);
+        __builtin_amdgcn_s_barrier();
+        for (int ks = 0; ks < nks; ++ks) {
+            // refill the slot whose reads finished before the barrier that ended step ks-1
+            if (issued < nks) gissue();
+            const char* st = smem + (ks % NS) * STAGE;
+            mfma_step(st, st + A_BYTES);
+            retire(issued - ks - 2);       // this wave's share of step ks+1 has landed ...
+            __builtin_amdgcn_s_barrier();  // ... and everybody else's
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may be in flight when the epilogue reuses LDS
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -334,22 +407,22 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int MINW>
+template <int BM, int BN, int WM, int WN, int BK, int MINW, int NS = 0>
 void launch_cfg(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab, hipStream_t s) {
     const long M = (long)g.B * g.nOH * g.nOW;
     const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = (g.N + BN - 1) / BN;
-    size_t lds = (size_t)2 * (BM + BN) * BK * 2;                      // double-buffered operand tiles
+    size_t lds = (size_t)(NS > 0 ? NS : 2) * (BM + BN) * BK * 2;       // operand stage buffers
     const size_t epi = (size_t)BM * BN * 2 + (size_t)4 * BN * 2 * 4;  // staged output tile + stats scratch (4 waves)
     if (lds < epi) lds = epi;
     const uint32_t xb = (uint32_t)((long)g.B * g.Hin * g.Win * (g.pix_elems ? g.pix_elems : g.C) * 2);
     const uint32_t wb = (uint32_t)((long)g.N * g.wtaps * g.C * 2);
     static bool attr_set = false;
     if (!attr_set) {
-        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<BM, BN, WM, WN, BK, MINW>),
+        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<BM, BN, WM, WN, BK, MINW, NS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, BK, MINW>), dim3(m_tiles * n_tiles), dim3(256), lds, s, (const bf16*)x,
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, BK, MINW, NS>), dim3(m_tiles * n_tiles), dim3(256), lds, s, (const bf16*)x,
                        (const bf16*)w, (bf16*)y, g, stats_slab, m_tiles, n_tiles, xb, wb);
 }
 
@@ -373,14 +446,35 @@ void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g,
                        hipStream_t s) {
     const bool n128 = g.N % 128 == 0;
     if (g.C % 64 != 0) {  // 32-channel K rows (the packed stem): only the BK = 32 tiles apply
-        if (n128) launch_cfg<128, 128, 2, 2, 32, 3>(x, w, y, g, stats_slab, s);
-        else launch_cfg<128, 64, 4, 1, 32, 3>(x, w, y, g, stats_slab, s);
+        if (n128) launch_cfg<128, 128, 2, 2, 32, 3, 3>(x, w, y, g, stats_slab, s);
+        else launch_cfg<128, 64, 4, 1, 32, 3, 3>(x, w, y, g, stats_slab, s);
         return;
     }
     switch (igemm_cfg_override()) {  // experiment knob; 0 = tuned default.  All configs use BM = 128.
+        case 9:  // the register-staged choice of the first round-1 builds (for A/B runs)
+            if (g.ntaps == 1 && g.C <= 1024) {
+                if (n128) launch_cfg<128, 128, 2, 2, 32, 3>(x, w, y, g, stats_slab, s);
+                else launch_cfg<128, 64, 4, 1, 32, 3>(x, w, y, g, stats_slab, s);
+            } else {
+                if (n128) launch_cfg<128, 128, 2, 2, 64, 2>(x, w, y, g, stats_slab, s);
+                else launch_cfg<128, 64, 4, 1, 64, 2>(x, w, y, g, stats_slab, s);
+            }
+            return;
         case 5:  // BK=64 everywhere (the round-1 baseline)
             if (n128) launch_cfg<128, 128, 2, 2, 64, 2>(x, w, y, g, stats_slab, s);
             else launch_cfg<128, 64, 4, 1, 64, 2>(x, w, y, g, stats_slab, s);
+            return;
+        case 6:  // LDS-DMA ring, BK=32, 4 stages (64 KB: two workgroups per CU)
+            if (n128) launch_cfg<128, 128, 2, 2, 32, 2, 4>(x, w, y, g, stats_slab, s);
+            else launch_cfg<128, 64, 4, 1, 32, 2, 4>(x, w, y, g, stats_slab, s);
+            return;
+        case 7:  // LDS-DMA ring, BK=64, 3 stages (96 KB: one workgroup per CU)
+            if (n128) launch_cfg<128, 128, 2, 2, 64, 1, 3>(x, w, y, g, stats_slab, s);
+            else launch_cfg<128, 64, 4, 1, 64, 1, 3>(x, w, y, g, stats_slab, s);
+            return;
+        case 8:  // LDS-DMA ring, BK=32, 3 stages
+            if (n128) launch_cfg<128, 128, 2, 2, 32, 3, 3>(x, w, y, g, stats_slab, s);
+            else launch_cfg<128, 64, 4, 1, 32, 3, 3>(x, w, y, g, stats_slab, s);
             return;
         case 1:  // BK=32, 3 waves/SIMD
             if (n128) launch_cfg<128, 128, 2, 2, 32, 3>(x, w, y, g, stats_slab, s);
@@ -397,14 +491,20 @@ void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g,
             launch_cfg<128, 64, 4, 1, 32, 4>(x, w, y, g, stats_slab, s);
             return;
         default:
-            // measured on MI355X (profiles/r1_igemm_cfg_sweep.md): short-K pointwise GEMMs are HBM/latency
-            // bound and want occupancy (BK=32, 4 blocks/CU); long-K ones want the deeper BK=64 step
-            if (g.ntaps == 1 && g.C <= 1024) {
-                if (n128) launch_cfg<128, 128, 2, 2, 32, 3>(x, w, y, g, stats_slab, s);
-                else launch_cfg<128, 64, 4, 1, 32, 3>(x, w, y, g, stats_slab, s);
-            } else {
+            // measured per ResNet-50 layer shape on MI355X at B=256 (profiles/r1_igemm_cfg_sweep.md,
+            // profiles/r1_igemm_glds_vs_regstage.md): the LDS-DMA ring (BK=32, 3 stages, 3 workgroups per CU) wins
+            // on every pointwise layer and on the 128-channel 3x3s; long-K 3x3s with >= 256 channels want the
+            // 4-stage ring at 2 workgroups per CU; the 64-channel 3x3 (9 short taps) keeps the register-staged
+            // BK=64 loop
+            if (g.ntaps > 1 && g.C == 64) {
                 if (n128) launch_cfg<128, 128, 2, 2, 64, 2>(x, w, y, g, stats_slab, s);
                 else launch_cfg<128, 64, 4, 1, 64, 2>(x, w, y, g, stats_slab, s);
+            } else if (g.ntaps > 1 && g.C >= 256) {
+                if (n128) launch_cfg<128, 128, 2, 2, 32, 2, 4>(x, w, y, g, stats_slab, s);
+                else launch_cfg<128, 64, 4, 1, 32, 2, 4>(x, w, y, g, stats_slab, s);
+            } else {
+                if (n128) launch_cfg<128, 128, 2, 2, 32, 3, 3>(x, w, y, g, stats_slab, s);
+                else launch_cfg<128, 64, 4, 1, 32, 3, 3>(x, w, y, g, stats_slab, s);
             }
     }
 }

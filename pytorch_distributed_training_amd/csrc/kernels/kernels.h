@@ -112,7 +112,12 @@ struct ConvGeom {
     int is;  // input step per output index: in_h = i*is + dh[t]
     int ntaps;        // taps of this launch
     int wtaps;        // T of the weight tensor [N][wtaps][C]
-    int8_t dh[kMaxTaps], dw[kMaxTaps], wslot[kMaxTaps];
+    // per tap: input offsets dh, dw (signed bytes) and the weight slot, packed in ONE dword so that the kernels
+    // fetch a tap with a scalar load at a runtime index (byte tables would become vector loads)
+    int32_t tap[kMaxTaps];
+    void set_tap(int t, int dh, int dw, int wslot) {
+        tap[t] = (dh & 0xff) | ((dw & 0xff) << 8) | ((wslot & 0xff) << 16);
+    }
     // optional bf16 tensor with the output's shape that is added in the epilogue (fuses the residual
     // branch's gradient into the data-gradient kernel instead of a separate elementwise add)
     const void* addend;
