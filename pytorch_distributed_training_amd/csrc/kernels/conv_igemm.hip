@@ -262,11 +262,13 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     constexpr int CH = BN / 8;          // 16-B chunks per output row
     constexpr int ORPP = 256 / CH;      // output rows per pass
     constexpr int NPASS = BM / ORPP;
+    constexpr bool PREFETCH = NPASS <= 8;  // taller tiles keep their accumulators' registers and load in the loop
+    constexpr int NPF = PREFETCH ? NPASS : 1;
     const int orow = tid / CH, och = tid % CH;
     const int ncol = tile_n * BN + och * 8;
-    bf16x8 bx[NPASS];
-    unsigned bbits[NPASS];
-    if (bnr) {
+    bf16x8 bx[NPF];
+    unsigned bbits[NPF];
+    if (bnr && PREFETCH) {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             const long m = (long)tile_m * BM + p * ORPP + orow;  // bnr launches are dense stride-1: pixel == m
@@ -360,8 +362,15 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                 for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)a[k]);
             }
             if (bnr) {
-                const bf16x8 xv = bx[p];
-                const unsigned bits = bbits[p];
+                bf16x8 xv;
+                unsigned bits;
+                if constexpr (PREFETCH) {
+                    xv = bx[p];
+                    bits = bbits[p];
+                } else {
+                    xv = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.bnr_x) + pix * g.N + ncol);
+                    bits = g.bnr_mask[(pix * g.N + ncol) >> 3];
+                }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const float gg = ((bits >> k) & 1u) ? (float)v[k] : 0.f;
@@ -436,10 +445,35 @@ int igemm_cfg_override() {
 
 }  // namespace
 
+namespace {
+// 256x128 tile (each wave 128x64: 0.75 LDS fragment reads and 25 % fewer staged bytes per MFMA than 128x128) pays on
+// long-K GEMMs once there are enough tiles to fill the chip: measured +15-25 % on the 256-channel 3x3s and the
+// K >= 1024 pointwise layers, a loss on short-K / few-tile shapes (profiles/r1_igemm_glds_vs_regstage.md)
+bool use_tall_tile(const ConvGeom& g) {
+    static const bool enabled = [] {
+        const char* e = std::getenv("PDT_IGEMM_TALL");
+        return !(e && e[0] == '0');
+    }();
+    if (!enabled) return false;
+    const long M = (long)g.B * g.nOH * g.nOW;
+    return g.N % 128 == 0 && g.C % 64 == 0 && (long)g.ntaps * g.C >= 1024 && (M / 256) * (g.N / 128) >= 256;
+}
+// rows of the output tile the launch heuristic below picks for this geometry (the slab of per-m-tile partial
+// rows the bindings allocate has one row per tile)
+int igemm_bm(const ConvGeom& g) {
+    const int cfg = igemm_cfg_override();
+    const bool n128 = g.N % 128 == 0;
+    if (cfg == 10) return n128 ? 256 : 128;
+    if (cfg != 0) return 128;
+    return use_tall_tile(g) ? 256 : 128;
+}
+}  // namespace
+
 int conv_igemm_m_tiles(const ConvGeom& g, int* bm_out) {
     const long M = (long)g.B * g.nOH * g.nOW;
-    if (bm_out) *bm_out = 128;
-    return (int)((M + 127) / 128);
+    const int bm = igemm_bm(g);
+    if (bm_out) *bm_out = bm;
+    return (int)((M + bm - 1) / bm);
 }
 
 void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab,
@@ -463,6 +497,10 @@ void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g,
         case 5:  // BK=64 everywhere (the round-1 baseline)
             if (n128) launch_cfg<128, 128, 2, 2, 64, 2>(x, w, y, g, stats_slab, s);
             else launch_cfg<128, 64, 4, 1, 64, 2>(x, w, y, g, stats_slab, s);
+            return;
+        case 10:  // LDS-DMA ring, 256x128 tile (each wave 128x64), BK=32, 3 stages (72 KB: two workgroups per CU)
+            if (n128) launch_cfg<256, 128, 2, 2, 32, 2, 3>(x, w, y, g, stats_slab, s);
+            else launch_cfg<128, 64, 4, 1, 32, 3, 3>(x, w, y, g, stats_slab, s);
             return;
         case 6:  // LDS-DMA ring, BK=32, 4 stages (64 KB: two workgroups per CU)
             if (n128) launch_cfg<128, 128, 2, 2, 32, 2, 4>(x, w, y, g, stats_slab, s);
@@ -496,7 +534,9 @@ void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g,
             // on every pointwise layer and on the 128-channel 3x3s; long-K 3x3s with >= 256 channels want the
             // 4-stage ring at 2 workgroups per CU; the 64-channel 3x3 (9 short taps) keeps the register-staged
             // BK=64 loop
-            if (g.ntaps > 1 && g.C == 64) {
+            if (use_tall_tile(g)) {
+                launch_cfg<256, 128, 2, 2, 32, 2, 3>(x, w, y, g, stats_slab, s);
+            } else if (g.ntaps > 1 && g.C == 64) {
                 if (n128) launch_cfg<128, 128, 2, 2, 64, 2>(x, w, y, g, stats_slab, s);
                 else launch_cfg<128, 64, 4, 1, 64, 2>(x, w, y, g, stats_slab, s);
             } else if (g.ntaps > 1 && g.C >= 256) {
