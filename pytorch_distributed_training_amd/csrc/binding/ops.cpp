@@ -504,6 +504,7 @@ std::tuple<Tensor, Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::opt
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor dx = at::empty_like(x), dres;
     Tensor sums = at::empty({2, C}, psums.options());
+    Tensor coef = at::empty({3, C}, psums.options());
     void* drp = nullptr;
     if (want_dres) {
         dres = at::empty_like(x);
@@ -511,7 +512,8 @@ std::tuple<Tensor, Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::opt
     }
     launch_bn_bwd_elemt(dz.data_ptr(), zp, x.data_ptr(), dx.data_ptr(), drp, M, (int)C, mean.data_ptr<float>(),
                         invstd.data_ptr<float>(), gamma.data_ptr<float>(), psums.data_ptr<float>(), (int)psums.size(0),
-                        sums.data_ptr<float>(), (float)count, count_ptr(count_dev), relu ? 1 : 0, cur_stream(x));
+                        sums.data_ptr<float>(), (float)count, count_ptr(count_dev), relu ? 1 : 0,
+                        coef.data_ptr<float>(), cur_stream(x));
     return {dx, dres, sums};
 }
 

@@ -10,6 +10,7 @@
 // Access pattern: NHWC makes the channel the fastest axis, so a thread owns 8 consecutive
 // channels (one 16 B load) and walks rows; its per-channel coefficients stay in registers.
 // The cross-row reductions are deterministic (LDS tree + partial slab, no float atomics).
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -17,6 +18,7 @@ namespace pdt {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr long kElemtTableBlocks = 4096;  // bwd_elemt: above this many chunks the coefficient table pays
 constexpr int kUnroll = 4;  // rows per thread and trip in the streaming kernels
 
 struct Map {
@@ -166,9 +168,12 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ 
         }
     }
     // grid-stride rows (the whole grid walks memory front to back), kUnroll rows per trip with all their loads
-    // issued before the first use: enough bytes in flight per CU to cover HBM latency
-    const long S = (long)gridDim.x * m.R;
-    for (long rb = (long)blockIdx.x * m.R + m.rl; rb < M; rb += kUnroll * S) {
+    // issued before the first use: enough bytes in flight per CU to cover HBM latency.  The rows of a trip are
+    // adjacent, so at any moment the grid touches ONE contiguous window per tensor: with S-strided rows the same
+    // kernels ran at 4.3 TB/s where a plain 2R+1W add reaches 6 (bench/micro/hbm_ceiling.py)
+    const long S = m.R;                       // a trip of a block covers kUnroll * R ADJACENT rows ...
+    const long T = (long)gridDim.x * kUnroll * m.R;  // ... and the grid one contiguous window (few DRAM streams)
+    for (long rb = (long)blockIdx.x * kUnroll * m.R + m.rl; rb < M; rb += T) {
         bf16x8 v[kUnroll], rv[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -215,8 +220,9 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const bf16* __restri
     ld8f(mean + m.cg * 8, mu);
     ld8f(invstd + m.cg * 8, is);
     float s0[8] = {0}, s1[8] = {0};
-    const long S = (long)gridDim.x * m.R;
-    for (long rb = (long)blockIdx.x * m.R + m.rl; rb < M; rb += kUnroll * S) {
+    const long S = m.R;                       // a trip of a block covers kUnroll * R ADJACENT rows ...
+    const long T = (long)gridDim.x * kUnroll * m.R;  // ... and the grid one contiguous window (few DRAM streams)
+    for (long rb = (long)blockIdx.x * kUnroll * m.R + m.rl; rb < M; rb += T) {
         bf16x8 g[kUnroll], xv[kUnroll];
         unsigned bits[kUnroll];
 #pragma unroll
@@ -244,6 +250,32 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const bf16* __restri
     block_reduce_store(m, C, s0, s1, slab);
 }
 
+// Per-channel coefficient table [3][C] of k_bn_bwd_elemt plus the summed [2][C] (second reduction level):
+// launched ahead of the streaming kernel when that one runs one chunk per block and a per-block
+// prologue over nps partial rows would cost as much as the chunk.
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_coef(const float* __restrict__ psums, int nps, int C,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, float count,
+                                                          const float* __restrict__ count_dev,
+                                                          float* __restrict__ sums_out, float* __restrict__ coef) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    float sa = 0.f, sb = 0.f;
+    for (int p = 0; p < nps; ++p) {  // fixed order -> deterministic
+        sa += psums[(long)p * 2 * C + c];
+        sb += psums[(long)p * 2 * C + C + c];
+    }
+    sums_out[c] = sa;
+    sums_out[C + c] = sb;
+    const float invn = 1.f / (count_dev ? count_dev[0] : count);
+    const float is = invstd[c], g_is = gamma[c] * is;
+    const float c1 = sa * invn, c2 = sb * invn;
+    coef[c] = g_is;
+    coef[C + c] = -g_is * c2 * is;
+    coef[2 * C + c] = g_is * (c2 * is * mean[c] - c1);
+}
+
 // dx = k1*dzm + k2*x + k3 with per-channel k's (see host comment); dres = dzm
 template <bool RELU, bool DRES>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restrict__ dz, const uint8_t* __restrict__ mask,
@@ -254,11 +286,16 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ psums, int nps,
                                                            float* __restrict__ sums_out, float count,
-                                                           const float* __restrict__ count_dev) {
+                                                           const float* __restrict__ count_dev,
+                                                           const float* __restrict__ coef) {
     const Map m = make_map(C);
-    const float invn = 1.f / (count_dev ? count_dev[0] : count);
     float k1[8], k2[8], k3[8];
-    {
+    if (coef != nullptr) {  // big tensors: k_bn_bwd_coef made the table, a block only streams its one chunk
+        ld8f(coef + m.cg * 8, k1);
+        ld8f(coef + C + m.cg * 8, k2);
+        ld8f(coef + 2 * C + m.cg * 8, k3);
+    } else {
+        const float invn = 1.f / (count_dev ? count_dev[0] : count);
         float mu[8], is[8], ga[8], sa[8] = {0}, sb[8] = {0};
         ld8f(mean + m.cg * 8, mu);
         ld8f(invstd + m.cg * 8, is);
@@ -290,8 +327,9 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
             k3[k] = g_is * (c2 * is[k] * mu[k] - c1);
         }
     }
-    const long S = (long)gridDim.x * m.R;
-    for (long rb = (long)blockIdx.x * m.R + m.rl; rb < M; rb += kUnroll * S) {
+    const long S = m.R;                       // a trip of a block covers kUnroll * R ADJACENT rows ...
+    const long T = (long)gridDim.x * kUnroll * m.R;  // ... and the grid one contiguous window (few DRAM streams)
+    for (long rb = (long)blockIdx.x * kUnroll * m.R + m.rl; rb < M; rb += T) {
         bf16x8 g[kUnroll], xv[kUnroll];
         unsigned bits[kUnroll];
 #pragma unroll
@@ -323,6 +361,20 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
     }
 }
 
+// Grid of the streaming kernels: ONE chunk (kUnroll * R adjacent rows, 16 KiB per tensor) per block, blocks
+// dispatched in order -> the chip walks each tensor front to back like a plain vectorised elementwise
+// kernel does (5.8 TB/s; a 2048-block grid-stride loop over the same rows reached 5.1, hbm_ceiling.py).
+long stream_blocks(long M, int R, long cap) {
+    static const long env_cap = [] {
+        const char* e = getenv("PDT_BN_GRID_CAP");
+        return e ? atol(e) : 0L;
+    }();
+    if (env_cap > 0) cap = env_cap;
+    long blocks = (M + (long)R * kUnroll - 1) / ((long)R * kUnroll);
+    if (cap > 0 && blocks > cap) blocks = cap;
+    return blocks < 1 ? 1 : blocks;
+}
+
 int grid_for(long M, int C) {
     const int R = kThreads / (C >> 3);
     long parts = (M + (long)R * 16 - 1) / ((long)R * 16);
@@ -350,9 +402,7 @@ void launch_bn_finalize(const float* stats, int nparts, int C, float count, cons
 void launch_bn_apply(const void* x, const void* residual, void* z, uint8_t* mask, long M, int C, const float* mean,
                      const float* invstd, const float* gamma, const float* beta, int relu, hipStream_t s) {
     const int R = kThreads / (C >> 3);
-    long blocks = (M + (long)R * 8 - 1) / ((long)R * 8);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
+    const long blocks = stream_blocks(M, R, 0);
     dim3 grid((int)blocks), block(kThreads);
 #define PDT_APPLY(RELU, RES)                                                                                    \
     hipLaunchKernelGGL((k_bn_apply<RELU, RES>), grid, block, 0, s, (const bf16*)x, (const bf16*)residual, (bf16*)z, \
@@ -377,16 +427,23 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, 
 
 void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx, void* dres, long M, int C,
                          const float* mean, const float* invstd, const float* gamma, const float* psums, int nps,
-                         float* sums_out, float count, const float* count_dev, int relu, hipStream_t s) {
+                         float* sums_out, float count, const float* count_dev, int relu, float* coef,
+                         hipStream_t s) {
     const int R = kThreads / (C >> 3);
-    long blocks = (M + (long)R * 8 - 1) / ((long)R * 8);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
+    // small tensors: one launch, <= 2048 blocks each folding the nps partial rows in its prologue;
+    // big ones (coef workspace given): table kernel first, then one chunk per block
+    const bool table = coef != nullptr && stream_blocks(M, R, 0) > kElemtTableBlocks;
+    if (table)
+        hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, s, psums, nps, C,
+                           mean, invstd, gamma, count, count_dev, sums_out, coef);
+    else
+        coef = nullptr;
+    const long blocks = stream_blocks(M, R, table ? 0 : 2048);
     dim3 grid((int)blocks), block(kThreads);
 #define PDT_ELEMT(RELU, DRES)                                                                                  \
     hipLaunchKernelGGL((k_bn_bwd_elemt<RELU, DRES>), grid, block, 0, s, (const bf16*)dz, (const uint8_t*)z,       \
                        (const bf16*)x, (bf16*)dx, (bf16*)dres, M, C, mean, invstd, gamma, psums, nps, sums_out, count,   \
-                       count_dev)
+                       count_dev, coef)
     if (relu && dres) PDT_ELEMT(true, true);
     else if (relu) PDT_ELEMT(true, false);
     else if (dres) PDT_ELEMT(false, true);

@@ -75,7 +75,7 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, 
 void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx, void* dres, long M, int C,
                          const float* mean, const float* invstd, const float* gamma, const float* psums /*[nps][2][C]*/,
                          int nps, float* sums_out /*[2][C] or null*/, float count, const float* count_dev, int relu,
-                         hipStream_t s);
+                         float* coef /*[3][C] workspace or null*/, hipStream_t s);
 
 // ---- LayerNorm over the last dim of [M, D] bf16 (layernorm.hip) -----------------------------------
 bool layernorm_dim_ok(int D);
