@@ -1,6 +1,7 @@
 // Torch bindings of the gfx950 kernels: validate operands on the host (a faulting kernel can
 // take the whole node down, so every shape / dtype / layout / size assumption of a kernel is
 // checked here), allocate outputs through the caching allocator, launch on the current stream.
+#include <algorithm>
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
@@ -47,8 +48,8 @@ Tensor reduce_slab(const Tensor& slab, int nparts, long n) {
     Tensor out = at::empty({n}, slab.options());
     Tensor tmp;
     float* tmp_ptr = nullptr;
-    // two levels only when the output is too narrow to fill the chip with column blocks
-    if (nparts > 64 && n < 64 * 256) {
+    // two levels when the column blocks alone (256 floats each) do not fill the chip
+    if (nparts > 64 && n < 512 * 256) {
         tmp = at::empty({kReduceChunks, n}, slab.options());
         tmp_ptr = tmp.data_ptr<float>();
     }
@@ -61,8 +62,19 @@ constexpr int kMaxFinalizeRows = 512;  // rows the consumer kernels (bn_finalize
 // [nparts][n] -> [<= max_rows][n]: first reduction level only (the consumer kernel fuses the second)
 Tensor shrink_rows(const Tensor& slab, int nparts, long n, int max_rows) {
     if (nparts <= max_rows) return slab;
+    const float* src = slab.data_ptr<float>();
+    Tensor mid;
+    // narrow rows, many of them (BN statistics of a 56x56 layer at batch 1024: 25 088 rows of 128 floats): 32
+    // chunk blocks would read the 12 MB alone, so a first pass with ~1024 blocks brings the row count down
+    const int colblocks = (int)((n + 255) / 256);
+    if (nparts >= 2048 && colblocks * kReduceChunks < 512) {
+        const int chunks = std::min(1024 / colblocks, nparts / 8);
+        mid = at::empty({chunks, n}, slab.options());
+        nparts = launch_reduce_rows_l1(src, nparts, n, (int)n, mid.data_ptr<float>(), chunks, cur_stream(slab));
+        src = mid.data_ptr<float>();
+    }
     Tensor out = at::empty({kReduceChunks, n}, slab.options());
-    const int rows = launch_reduce_rows_l1(slab.data_ptr<float>(), nparts, n, (int)n, out.data_ptr<float>(),
+    const int rows = launch_reduce_rows_l1(src, nparts, n, (int)n, out.data_ptr<float>(), kReduceChunks,
                                            cur_stream(slab));
     return out.narrow(0, 0, rows);
 }

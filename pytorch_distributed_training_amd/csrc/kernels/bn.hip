@@ -259,12 +259,24 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_coef(const float* __restric
                                                           const float* __restrict__ gamma, float count,
                                                           const float* __restrict__ count_dev,
                                                           float* __restrict__ sums_out, float* __restrict__ coef) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= C) return;
+    // 32 channels per block, 8 lanes per channel over the partial rows (fixed order -> deterministic)
+    __shared__ float red[8][32][2];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float sa = 0.f, sb = 0.f;
-    for (int p = 0; p < nps; ++p) {  // fixed order -> deterministic
-        sa += psums[(long)p * 2 * C + c];
-        sb += psums[(long)p * 2 * C + C + c];
+    if (c < C)
+        for (int p = pl; p < nps; p += 8) {
+            sa += psums[(long)p * 2 * C + c];
+            sb += psums[(long)p * 2 * C + C + c];
+        }
+    red[pl][cl][0] = sa;
+    red[pl][cl][1] = sb;
+    __syncthreads();
+    if (pl != 0 || c >= C) return;
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+        sa += red[r][cl][0];
+        sb += red[r][cl][1];
     }
     sums_out[c] = sa;
     sums_out[C + c] = sb;
@@ -434,7 +446,7 @@ void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx,
     // big ones (coef workspace given): table kernel first, then one chunk per block
     const bool table = coef != nullptr && stream_blocks(M, R, 0) > kElemtTableBlocks;
     if (table)
-        hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, s, psums, nps, C,
+        hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 31) / 32), dim3(kThreads), 0, s, psums, nps, C,
                            mean, invstd, gamma, count, count_dev, sums_out, coef);
     else
         coef = nullptr;

@@ -404,9 +404,10 @@ void launch_reduce_slab(const float* slab, int nparts, long stride, int n, float
     }
 }
 
-int launch_reduce_rows_l1(const float* slab, int nparts, long stride, int n, float* out, hipStream_t s) {
+int launch_reduce_rows_l1(const float* slab, int nparts, long stride, int n, float* out, int max_chunks,
+                          hipStream_t s) {
     const int colblocks = (n + 255) / 256;
-    const int ppc = (nparts + kReduceChunks - 1) / kReduceChunks;
+    const int ppc = (nparts + max_chunks - 1) / max_chunks;
     const int chunks = (nparts + ppc - 1) / ppc;
     hipLaunchKernelGGL(k_reduce_slab, dim3(colblocks, chunks), dim3(256), 0, s, slab, nparts, stride, n, ppc, out);
     return chunks;

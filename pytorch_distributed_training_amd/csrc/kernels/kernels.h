@@ -51,8 +51,9 @@ void launch_multi_transpose(const TransposeArgs& a, hipStream_t s);
 // workspace, required when nparts > 64 (two-level reduction).
 constexpr int kReduceChunks = 32;
 void launch_reduce_slab(const float* slab, int nparts, long stride, int n, float* out, float* tmp, hipStream_t s);
-// first level only: out[kReduceChunks][n] gets <= kReduceChunks partial rows; returns the row count
-int launch_reduce_rows_l1(const float* slab, int nparts, long stride, int n, float* out, hipStream_t s);
+// first level only: out[max_chunks][n] gets <= max_chunks partial rows; returns the row count
+int launch_reduce_rows_l1(const float* slab, int nparts, long stride, int n, float* out, int max_chunks,
+                          hipStream_t s);
 
 // ---- softmax cross-entropy (mean), fwd + bwd in one pass -------------------------------------
 void launch_softmax_ce(const void* logits, int dtype, const int64_t* labels, int B, int N, float* row_loss,

@@ -48,6 +48,30 @@ def make_rccl_comm(group=None, high_priority: bool = True):
     return comm
 
 
+def _rccl_or_none(process_group, world: int, device):
+    """The job's own communicator, or None (-> the reducer all-reduces through the c10d group instead) when
+    ``PDT_COMM=torch`` asks for that or when ANY rank failed to create it: the ranks agree on the outcome
+    through the c10d group, so a node whose RCCL bootstrap fails degrades the whole job, not one rank."""
+    if os.environ.get("PDT_COMM", "native").lower() == "torch" and world > 1:
+        return None
+    if world == 1:
+        return make_rccl_comm(process_group, high_priority=True)  # None unless PDT_FORCE_COMM=1
+    comm, err = None, None
+    try:
+        comm = make_rccl_comm(process_group, high_priority=True)
+    except Exception as e:  # noqa: BLE001 - reported below, then every rank takes the c10d path
+        err = e
+    ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=device)
+    tdist.all_reduce(ok, op=tdist.ReduceOp.MIN, group=process_group)
+    if int(ok.item()) == 1:
+        return comm
+    if tdist.get_rank(process_group) == 0 or err is not None:
+        print(f"[pdt] native RCCL communicator unavailable ({err!r}); all-reducing through torch.distributed",
+              flush=True)
+    _shared_comm.pop((id(process_group), True), None)
+    return None
+
+
 class NativeReducer:
     def __init__(self, params, comm, bucket_cap_bytes: int, first_bucket_bytes: int, grad_dtype=None,
                  gradient_as_bucket_view: bool = True, names=None, process_group=None):
@@ -60,8 +84,8 @@ class NativeReducer:
         self.rccl = None
         pg = None
         if self.device.type == "cuda":
-            self.rccl = make_rccl_comm(process_group, high_priority=True)  # None at world 1 unless PDT_FORCE_COMM=1
-        elif self.world > 1:
+            self.rccl = _rccl_or_none(process_group, self.world, self.device)
+        if self.rccl is None and self.world > 1:  # gloo, or the c10d RCCL group when the own communicator is off
             pg = process_group if process_group is not None else tdist.distributed_c10d._get_default_group()
         self._r = C.Reducer(self.params, names, self.rccl, pg, self.world, int(bucket_cap_bytes),
                             int(first_bucket_bytes), grad_dtype, bool(gradient_as_bucket_view))
