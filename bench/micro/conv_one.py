@@ -1,0 +1,40 @@
+"""Run a few ResNet-50 conv shapes (fwd / dgrad / wgrad) a handful of times: the target of rocprofv3 --pmc passes.
+
+    python bench/micro/conv_one.py --batch 1024 --shapes 64,56,64,3,1 256,14,256,3,1 64,56,256,1,1
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pytorch_distributed_training_amd.ops import native  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--shapes", nargs="+", default=["64,56,64,3,1", "256,14,256,3,1", "64,56,256,1,1", "256,56,64,1,1"])
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for spec in a.shapes:
+        cin, h, cout, k, s = (int(v) for v in spec.split(","))
+        pad = k // 2
+        x = torch.randn(a.batch, cin, h, h, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout, cin, k, k, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        y = native.conv2d_fwd(x, w, s, pad, True)[0]
+        dy = torch.randn_like(y)
+        for _ in range(a.iters):
+            native.conv2d_fwd(x, w, s, pad, True)
+            native.conv2d_dgrad(dy, w, tuple(x.shape), s, pad)
+            native.conv2d_wgrad(dy, x, tuple(w.shape), s, pad)
+        torch.cuda.synchronize()
+        print("done", spec, flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -36,6 +36,12 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), /*stride*/ 0, (int)bytes, 0x00020000);
 }
+// value of lane (l ^ 1): a DPP quad permute [1,0,3,2] -- one VALU move, no LDS permute, no address
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+
 __device__ __forceinline__ bf16x8 buffer_load_bf16x8(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
     return __builtin_bit_cast(bf16x8, v);

@@ -50,7 +50,7 @@ template <int BM, int BN, int WM, int WN, int BK, int MINW, int NS = 0>
 __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                        bf16* __restrict__ y, const ConvGeom g,
                                                        float* __restrict__ stats_slab, int m_tiles, int n_tiles,
-                                                       uint32_t x_bytes, uint32_t w_bytes) {
+                                                       uint32_t x_bytes, uint32_t w_bytes, int xcd_group) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int ROWB = BK * 2;           // bytes per LDS row
     constexpr int CPR = ROWB / 16;         // 16-B chunks per row = threads staging one row
@@ -283,26 +283,35 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        float csum = 0.f, csq = 0.f;
+        // Lanes l and l^1 hold columns (n, n+1) of the same rows r, r+1: one DPP exchange (a VALU move, no LDS
+        // permute) gives the even lane row r and the odd lane row r+1 of BOTH columns as fp32, which one
+        // v_cvt_pk_bf16_f32 rounds and packs into the dword the LDS tile takes.  The statistics are kept per
+        // (row parity, column) and the two lanes swap halves once at the end.
+        float slo = 0.f, shi = 0.f, qlo = 0.f, qhi = 0.f;
         const int col = wn * (BN / WN) + j * 32 + (lane & 31);
+        const int c2 = odd ? col - 1 : col;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int rbase = wm * (BM / WM) + i * 32 + 4 * khalf;
+            const int rbase = wm * (BM / WM) + i * 32 + 4 * khalf + (odd ? 1 : 0);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const bf16 b0 = (bf16)acc[i][j][r], b1 = (bf16)acc[i][j][r + 1];
-                const float f0 = (float)b0, f1 = (float)b1;
-                csum += f0 + f1;
-                csq += f0 * f0 + f1 * f1;
-                const uint32_t u0 = __builtin_bit_cast(uint16_t, b0), u1 = __builtin_bit_cast(uint16_t, b1);
-                const uint32_t recv = (uint32_t)__shfl_xor((int)(odd ? u0 : u1), 1, 64);
-                // even lane: row r, cols (n, n+1);  odd lane: row r+1, cols (n-1, n)
-                const uint32_t packed = odd ? (recv | (u1 << 16)) : (u0 | (recv << 16));
-                const int row = rbase + (r & 3) + 8 * (r >> 2) + (odd ? 1 : 0);
-                const int c2 = odd ? col - 1 : col;
+                const float a0 = acc[i][j][r], a1 = acc[i][j][r + 1];
+                const float recv = dpp_xor1(odd ? a0 : a1);
+                const bf16x2 pk = {(bf16)(odd ? recv : a0), (bf16)(odd ? a1 : recv)};
+                const uint32_t packed = __builtin_bit_cast(uint32_t, pk);
+                const float f0 = __builtin_bit_cast(float, packed << 16);
+                const float f1 = __builtin_bit_cast(float, packed & 0xffff0000u);
+                slo += f0;
+                shi += f1;
+                qlo += f0 * f0;
+                qhi += f1 * f1;
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
                 *reinterpret_cast<uint32_t*>(Os + row * OPITCH + c2 * 2) = packed;
             }
         }
+        // column n = even lane's lo + odd lane's lo, column n+1 = the two hi's
+        float csum = (odd ? shi : slo) + dpp_xor1(odd ? slo : shi);
+        float csq = (odd ? qhi : qlo) + dpp_xor1(odd ? qlo : qhi);
         if (fwd_stats) {
             csum += __shfl_xor(csum, 32, 64);
             csq += __shfl_xor(csq, 32, 64);
@@ -416,6 +425,16 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     }
 }
 
+// tiles per round-robin XCD group (0 = contiguous tile range per XCD); PDT_IGEMM_XCD_GROUP = m-tiles per group
+int xcd_group_tiles(const ConvGeom& g, int n_tiles) {
+    static const int env = [] {
+        const char* e = std::getenv("PDT_IGEMM_XCD_GROUP");
+        return e ? std::atoi(e) : 0;
+    }();
+    (void)g;
+    return env > 0 ? env * n_tiles : 0;
+}
+
 template <int BM, int BN, int WM, int WN, int BK, int MINW, int NS = 0>
 void launch_cfg(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab, hipStream_t s) {
     const long M = (long)g.B * g.nOH * g.nOW;
@@ -432,7 +451,7 @@ void launch_cfg(const void* x, const void* w, void* y, const ConvGeom& g, float*
         attr_set = true;
     }
     hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, BK, MINW, NS>), dim3(m_tiles * n_tiles), dim3(256), lds, s, (const bf16*)x,
-                       (const bf16*)w, (bf16*)y, g, stats_slab, m_tiles, n_tiles, xb, wb);
+                       (const bf16*)w, (bf16*)y, g, stats_slab, m_tiles, n_tiles, xb, wb, xcd_group_tiles(g, n_tiles));
 }
 
 int igemm_cfg_override() {
