@@ -75,6 +75,18 @@ __device__ __forceinline__ void lds_dma16(i32x4 rsrc, uint32_t byte_off, uint32_
         : "memory");
 }
 
+// same with a scalar byte offset added to every lane's address (buffer SOFFSET): a K loop that only moves along the
+// channel axis keeps its per-lane offsets and advances one SGPR
+__device__ __forceinline__ void lds_dma16s(i32x4 rsrc, uint32_t byte_off, uint32_t soffset_uniform,
+                                           uint32_t lds_addr_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(byte_off), "s"(rsrc), "s"(lds_addr_uniform), "s"(soffset_uniform)
+        : "memory");
+}
+
 constexpr uint32_t kOOB = 0x80000000u;  // > any legal byte offset (tensors are < 2 GiB, checked on the host)
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

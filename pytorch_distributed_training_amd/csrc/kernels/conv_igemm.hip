@@ -193,9 +193,11 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
         const i32x4 rxw = make_rsrc_words(x, x_bytes), rww = make_rsrc_words(w, w_bytes);
         const uint32_t lds0 = lds_address(smem) + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
         int ti = 0, ci = 0, issued = 0;
-        // issue the DMA loads of K-step `issued` into ring slot issued % NS
-        auto gissue = [&]() {
-            const uint32_t sa = lds0 + (uint32_t)((issued % NS) * STAGE);
+        // Per-lane byte offsets of this thread's 16-B chunks at channel 0 of the CURRENT tap (kOOB: the row is
+        // padding / past the end -> the DMA writes zeros).  They change only when the tap does; inside a tap the
+        // K loop advances the scalar SOFFSET of the loads, so a K-step costs no vector address arithmetic.
+        uint32_t aoff[PA], boff[PB];
+        auto enter_tap = [&]() {
             // the tap index must stay in a scalar register: a vector index into the kernel-argument table would turn
             // this read into a global load whose compiler-inserted vmcnt wait also drains the DMA ring
             const int tp = g.tap[__builtin_amdgcn_readfirstlane(ti)];
@@ -206,16 +208,26 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                 const int lchunk = chunk ^ ((row / RPB) & (CPR - 1));
                 const int hi = rih[p] + dh, wi = riw[p] + dw;
                 const bool ok = (unsigned)hi < (unsigned)g.Hin && (unsigned)wi < (unsigned)g.Win;
-                const uint32_t off = (uint32_t)(((rowpix[p] + hi * g.Win + wi) * pix_elems + ci + lchunk * 8) * 2);
-                lds_dma16(rxw, ok ? off : kOOB, sa + (uint32_t)(p * RPP * ROWB));
+                aoff[p] = ok ? (uint32_t)(((rowpix[p] + hi * g.Win + wi) * pix_elems + lchunk * 8) * 2) : kOOB;
             }
 #pragma unroll
             for (int p = 0; p < PB; ++p) {
                 const int row = p * RPP + lrow;
                 const int lchunk = chunk ^ ((row / RPB) & (CPR - 1));
-                const uint32_t off = ((wrow[p] + (uint32_t)ws) * (uint32_t)g.C + (uint32_t)(ci + lchunk * 8)) * 2u;
-                lds_dma16(rww, wrow[p] != 0xffffffffu ? off : kOOB, sa + (uint32_t)(A_BYTES + p * RPP * ROWB));
+                boff[p] = wrow[p] != 0xffffffffu
+                              ? ((wrow[p] + (uint32_t)ws) * (uint32_t)g.C + (uint32_t)(lchunk * 8)) * 2u
+                              : kOOB;
             }
+        };
+        // issue the DMA loads of K-step `issued` into ring slot issued % NS
+        auto gissue = [&]() {
+            const uint32_t sa = lds0 + (uint32_t)((issued % NS) * STAGE);
+            if (ci == 0) enter_tap();
+            const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(ci * 2);
+#pragma unroll
+            for (int p = 0; p < PA; ++p) lds_dma16s(rxw, aoff[p], soff, sa + (uint32_t)(p * RPP * ROWB));
+#pragma unroll
+            for (int p = 0; p < PB; ++p) lds_dma16s(rww, boff[p], soff, sa + (uint32_t)(A_BYTES + p * RPP * ROWB));
             ++issued;
             ci += BK;
             if (ci == g.C) {
