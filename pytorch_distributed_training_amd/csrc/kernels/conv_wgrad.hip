@@ -58,6 +58,10 @@ struct WgradArgs {
     long M, m_per_split;
     FastDiv div_wo, div_howo;
     uint32_t x_bytes, dy_bytes;
+    // KM pixels = kb images + kh rows + kw columns (of the OUTPUT grid), and what that is in X bytes for a fixed tap:
+    // xstep without carries, xwrap_w / xwrap_h the corrections when the column / row index wraps (mod 2^32)
+    int kh, kw;
+    uint32_t xstep, xwrap_w, xwrap_h;
 };
 
 template <int TNW, int TCW>
@@ -100,7 +104,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const bf16* __restrict__ 
     long m_end = m_begin + a.m_per_split;
     if (m_end > a.M) m_end = a.M;
 
-    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, a.dy_bytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, a.x_bytes);
 
     const int nrow = tid / CHN, nch = tid % CHN;
@@ -109,30 +112,54 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const bf16* __restrict__ 
     const bool n_ok = (n0 + nch * 8) < a.N;
     const bool c_ok = (c0 + cch * 8) < a.C;
 
+    // The K loop walks the pixels front to back, KM per step, so NO per-step address arithmetic is redone from
+    // scratch (the first version spent 3x the MFMA time in quarter-rate integer multiplies and 64-bit adds):
+    //  * dY rows are linear in the pixel index: the lane offsets are fixed and the buffer descriptor (scalar
+    //    registers) moves KM rows per step; its record count ends at the split's last row, so the ragged end
+    //    reads zeros.
+    //  * X rows need (ho, wo) for the padding test: each staged row carries (ho, wo, byte offset) and advances them
+    //    by the constant decomposition of KM pixels = a.kb images + a.kh rows + a.kw columns, with two carries.
+    uint32_t vn[PN];
+#pragma unroll
+    for (int p = 0; p < PN; ++p) vn[p] = n_ok ? (uint32_t)(((p * RPN + nrow) * a.N + n0 + nch * 8) * 2) : kOOB;
+    int xho[PC], xwo[PC];
+    uint32_t xoff[PC];
+#pragma unroll
+    for (int p = 0; p < PC; ++p) {
+        const uint32_t mm = (uint32_t)(m_begin + p * RPC + crow);
+        const uint32_t b = fdiv(mm, a.div_howo);
+        const uint32_t rem = mm - b * a.div_howo.d;
+        const uint32_t ho = fdiv(rem, a.div_wo);
+        const uint32_t wo = rem - ho * a.div_wo.d;
+        xho[p] = (int)ho;
+        xwo[p] = (int)wo;
+        const int hi = (int)ho * a.stride - a.pad + r, wi = (int)wo * a.stride - a.pad + s;
+        xoff[p] = (uint32_t)((((int)b * a.Hin + hi) * a.Win + wi) * a.C + c0 + cch * 8) * 2u;  // modular when hi/wi < 0
+    }
+    const int dr = r - a.pad, ds = s - a.pad;
+
     bf16x8 rn[PN], rc[PC];
     auto gload = [&](long mbase) {
+        const long left = m_end - mbase;
+        const __amdgpu_buffer_rsrc_t rdy = make_rsrc(reinterpret_cast<const char*>(dy) + mbase * a.N * 2,
+                                                     left > 0 ? (uint32_t)(left * a.N * 2) : 0u);
 #pragma unroll
-        for (int p = 0; p < PN; ++p) {
-            const long m = mbase + p * RPN + nrow;
-            const uint32_t off = (uint32_t)((m * a.N + n0 + nch * 8) * 2);
-            rn[p] = buffer_load_bf16x8(rdy, (m < m_end && n_ok) ? off : kOOB);
-        }
+        for (int p = 0; p < PN; ++p) rn[p] = buffer_load_bf16x8(rdy, vn[p]);
 #pragma unroll
         for (int p = 0; p < PC; ++p) {
-            const long m = mbase + p * RPC + crow;
-            uint32_t off = kOOB;
-            if (m < m_end && c_ok) {
-                const uint32_t mm = (uint32_t)m;
-                const uint32_t b = fdiv(mm, a.div_howo);
-                const uint32_t rem = mm - b * a.div_howo.d;
-                const uint32_t ho = fdiv(rem, a.div_wo);
-                const uint32_t wo = rem - ho * a.div_wo.d;
-                const int hi = (int)ho * a.stride - a.pad + r;
-                const int wi = (int)wo * a.stride - a.pad + s;
-                if ((unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win)
-                    off = (uint32_t)(((((long)b * a.Hin + hi) * a.Win + wi) * a.C + c0 + cch * 8) * 2);
-            }
-            rc[p] = buffer_load_bf16x8(rx, off);
+            const int hi = __mul24(xho[p], a.stride) + dr, wi = __mul24(xwo[p], a.stride) + ds;
+            const bool ok = c_ok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
+            rc[p] = buffer_load_bf16x8(rx, ok ? xoff[p] : kOOB);
+            // advance this row by KM pixels
+            int wo = xwo[p] + a.kw;
+            const bool cw = wo >= a.Wout;
+            wo -= cw ? a.Wout : 0;
+            int ho = xho[p] + a.kh + (cw ? 1 : 0);
+            const bool ch = ho >= a.Hout;
+            ho -= ch ? a.Hout : 0;
+            xwo[p] = wo;
+            xho[p] = ho;
+            xoff[p] += a.xstep + (cw ? a.xwrap_w : 0u) + (ch ? a.xwrap_h : 0u);
         }
     };
     auto lds_store = [&](int buf) {
@@ -218,6 +245,16 @@ void launch_cfg(const void* dy, const void* x, float* slab, const WgradGeom& g, 
     a.div_howo = make_fastdiv((uint32_t)(g.Hout * g.Wout));
     a.x_bytes = (uint32_t)((long)g.B * g.Hin * g.Win * g.C * 2);
     a.dy_bytes = (uint32_t)(a.M * g.N * 2);
+    {
+        const int hw = g.Hout * g.Wout;
+        const int kb = KM / hw, rem = KM % hw;
+        a.kh = rem / g.Wout;
+        a.kw = rem % g.Wout;
+        const uint32_t c2 = (uint32_t)g.C * 2u;
+        a.xstep = ((uint32_t)kb * g.Hin * g.Win + (uint32_t)a.kh * g.stride * g.Win + (uint32_t)a.kw * g.stride) * c2;
+        a.xwrap_w = ((uint32_t)g.stride * g.Win - (uint32_t)g.Wout * g.stride) * c2;
+        a.xwrap_h = ((uint32_t)g.Hin * g.Win - (uint32_t)g.Hout * g.stride * g.Win) * c2;
+    }
     const size_t lds = (size_t)2 * KM * (TNW + TCW) * 2;
     const int grid = a.n_tiles * a.c_tiles * g.KH * g.KW * g.splits;
     hipLaunchKernelGGL((k_conv_wgrad<TNW, TCW>), dim3(grid), dim3(256), lds, s, (const bf16*)dy, (const bf16*)x, slab,
