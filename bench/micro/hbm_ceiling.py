@@ -29,6 +29,8 @@ for B in (256, 1024):
     n = x.numel() * 2
     t = timeit(lambda: y.copy_(x))
     print(f"B={B} copy   {2 * n / t / 1e12:.2f} TB/s")
+    t = timeit(lambda: y.fill_(1.0))
+    print(f"B={B} fill   {n / t / 1e12:.2f} TB/s (write only)")
     t = timeit(lambda: torch.add(x, r, out=y))
     print(f"B={B} add    {3 * n / t / 1e12:.2f} TB/s")
     t = timeit(lambda: x.sum())

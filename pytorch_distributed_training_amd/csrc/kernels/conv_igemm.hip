@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     constexpr int CH = BN / 8;          // 16-B chunks per output row
     constexpr int ORPP = 256 / CH;      // output rows per pass
     constexpr int NPASS = BM / ORPP;
-    constexpr bool PREFETCH = NPASS <= 8;  // taller tiles keep their accumulators' registers and load in the loop
+    constexpr bool PREFETCH = NPASS <= 8 && MINW < 4;  // taller tiles (and the 128-register build) keep their registers and load in the loop
     constexpr int NPF = PREFETCH ? NPASS : 1;
     const int orow = tid / CH, och = tid % CH;
     const int ncol = tile_n * BN + och * 8;
@@ -466,6 +466,16 @@ void launch_cfg(const void* x, const void* w, void* y, const ConvGeom& g, float*
                        (const bf16*)w, (bf16*)y, g, stats_slab, m_tiles, n_tiles, xb, wb, xcd_group_tiles(g, n_tiles));
 }
 
+// A/B knob: fused-BN-reduce data gradients on the 128-register build too (its epilogue then loads x / mask inside
+// the store loop instead of prefetching them)
+bool bnr_lean() {
+    static const bool v = [] {
+        const char* e = std::getenv("PDT_IGEMM_BNR_LEAN");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
 int igemm_cfg_override() {
     static int v = [] {
         const char* e = std::getenv("PDT_IGEMM_CFG");
@@ -533,6 +543,14 @@ void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g,
             if (n128) launch_cfg<256, 128, 2, 2, 32, 2, 3>(x, w, y, g, stats_slab, s);
             else launch_cfg<128, 64, 4, 1, 32, 3, 3>(x, w, y, g, stats_slab, s);
             return;
+        case 11:  // double-buffered DMA (2 stages), 128-register build: four workgroups per CU for short-K layers
+            if (n128) launch_cfg<128, 128, 2, 2, 32, 4, 2>(x, w, y, g, stats_slab, s);
+            else launch_cfg<128, 64, 4, 1, 32, 4, 2>(x, w, y, g, stats_slab, s);
+            return;
+        case 12:  // ring of 3, 128-register build
+            if (n128) launch_cfg<128, 128, 2, 2, 32, 4, 3>(x, w, y, g, stats_slab, s);
+            else launch_cfg<128, 64, 4, 1, 32, 4, 3>(x, w, y, g, stats_slab, s);
+            return;
         case 6:  // LDS-DMA ring, BK=32, 4 stages (64 KB: two workgroups per CU)
             if (n128) launch_cfg<128, 128, 2, 2, 32, 2, 4>(x, w, y, g, stats_slab, s);
             else launch_cfg<128, 64, 4, 1, 32, 2, 4>(x, w, y, g, stats_slab, s);
@@ -565,11 +583,18 @@ void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g,
             // on every pointwise layer and on the 128-channel 3x3s; long-K 3x3s with >= 256 channels want the
             // 4-stage ring at 2 workgroups per CU; the 64-channel 3x3 (9 short taps) keeps the register-staged
             // BK=64 loop
+            // B=1024 re-sweep (bench/resnet50_roofline.py): short-K launches (K = taps x C <= 512: most pointwise
+            // layers, the parity launches of stride-2 data gradients) are latency-bound, so they take the
+            // 128-register build with a 2-stage DMA buffer = FOUR workgroups per CU (-5..-13 %); the 64-channel
+            // 3x3 takes the 128-register ring of 3 (-4 %).
             if (use_tall_tile(g)) {
                 launch_cfg<256, 128, 2, 2, 32, 2, 3>(x, w, y, g, stats_slab, s);
+            } else if ((long)g.ntaps * g.C <= 512 && (g.bnr_x == nullptr || bnr_lean())) {
+                if (n128) launch_cfg<128, 128, 2, 2, 32, 4, 2>(x, w, y, g, stats_slab, s);
+                else launch_cfg<128, 64, 4, 1, 32, 4, 2>(x, w, y, g, stats_slab, s);
             } else if (g.ntaps > 1 && g.C == 64) {
-                if (n128) launch_cfg<128, 128, 2, 2, 64, 2>(x, w, y, g, stats_slab, s);
-                else launch_cfg<128, 64, 4, 1, 64, 2>(x, w, y, g, stats_slab, s);
+                if (n128) launch_cfg<128, 128, 2, 2, 32, 4, 3>(x, w, y, g, stats_slab, s);
+                else launch_cfg<128, 64, 4, 1, 32, 4, 3>(x, w, y, g, stats_slab, s);
             } else if (g.ntaps > 1 && g.C >= 256) {
                 if (n128) launch_cfg<128, 128, 2, 2, 32, 2, 4>(x, w, y, g, stats_slab, s);
                 else launch_cfg<128, 64, 4, 1, 32, 2, 4>(x, w, y, g, stats_slab, s);
