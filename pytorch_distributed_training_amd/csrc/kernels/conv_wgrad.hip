@@ -25,7 +25,7 @@
 namespace pdt {
 namespace {
 
-constexpr int KM = 64;  // pixels (reduction rows) per K-step
+constexpr int KM = 32;  // pixels (reduction rows) per K-step
 
 template <int RB>
 __device__ __forceinline__ int swz_off(int row, int ch) {
@@ -65,7 +65,7 @@ struct WgradArgs {
 };
 
 template <int TNW, int TCW>
-__global__ __launch_bounds__(256, 2) void k_conv_wgrad(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+__global__ __launch_bounds__(256, 3) void k_conv_wgrad(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                        float* __restrict__ slab, const WgradArgs a) {
     constexpr int RBN = TNW * 2, RBC = TCW * 2;        // LDS row bytes
     constexpr int CHN = TNW / 8, CHC = TCW / 8;        // 16-B chunks per row
