@@ -36,6 +36,8 @@ namespace {
 
 constexpr int kYPitch = 192;  // bytes per dY row in LDS: 64 n x 2 B + 64 B pad (see bank note above)
 constexpr int max_slots(int mode) { return mode == 0 ? 6 : 8; }  // 16-B staging loads per thread and chunk
+constexpr int kMaxKP = 112;              // K rows (pixels) per chunk, a multiple of 16
+constexpr int kMaxKSteps = kMaxKP / 16;
 
 typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
 
@@ -85,9 +87,29 @@ __global__ __launch_bounds__(MODE == 0 ? 384 : 256, MODE == 0 ? 3 : 2) void k_wg
     int chunk_end = chunk_begin + a.chunks_per_split;
     if (chunk_end > a.total_chunks) chunk_end = a.total_chunks;
 
-    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, a.dy_bytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, a.x_bytes);
     const int cpp_mask = (1 << a.cpp_log2) - 1;
+
+    // Everything about a staging slot that does not depend on the chunk is computed ONCE: the dY lane offset
+    // (the chunk only moves the buffer descriptor, whose record count also cuts the ragged last rows of an
+    // image), and for a window slot its row inside the window, its byte offset relative to the window origin
+    // and whether its column lies in the image.  Per chunk a window slot then costs an add, two compares and a
+    // select instead of two divisions and a chain of multiplies.
+    uint32_t dyrel[kMaxSlots], xrel[kMaxSlots];
+    int xwr[kMaxSlots];
+    bool xcol_ok[kMaxSlots];
+#pragma unroll
+    for (int s = 0; s < kMaxSlots; ++s) {
+        const int id = tid + s * NT;
+        dyrel[s] = (uint32_t)(((id >> 3) * a.N + (id & 7) * 8) * 2);
+        const int j = tid + (s - a.sd) * NT;
+        const int cc = j & cpp_mask, pix = j >> a.cpp_log2;
+        const int wr = (int)fdiv((uint32_t)(pix < 0 ? 0 : pix), a.div_wcols);
+        const int ws = pix - wr * a.WCOLS - a.pw;
+        xwr[s] = wr;
+        xcol_ok[s] = j >= 0 && j < a.nch_x && (unsigned)ws < (unsigned)a.Ws;
+        xrel[s] = (uint32_t)(((wr * a.Ws + ws) * a.xpix + c0 + cc * 8) * 2);  // modular when ws < 0
+    }
 
     bf16x8 regs[kMaxSlots];
     auto stage_load = [&](int chunk) {
@@ -96,27 +118,19 @@ __global__ __launch_bounds__(MODE == 0 ? 384 : 256, MODE == 0 ? 3 : 2) void k_wg
         int rows = a.Ho - ho0;
         if (rows > a.R) rows = a.R;
         const int pvalid = rows * a.Wo;
-        const uint32_t dy_base = (uint32_t)((b * a.Ho + ho0) * a.Wo) * (uint32_t)a.N + (uint32_t)n0;
+        const long dy_base = (long)((b * a.Ho + ho0) * a.Wo) * a.N + n0;
+        // offsets row * N + nc * 8 (+8) of rows < pvalid end before pvalid * N - n0 because the tile fits (N % 64 == 0)
+        const __amdgpu_buffer_rsrc_t rdy =
+            make_rsrc(reinterpret_cast<const char*>(dy) + dy_base * 2, (uint32_t)((pvalid * a.N - n0) * 2));
         const int hs0 = ho0 * a.sh - a.ph;
+        const uint32_t xbase = (uint32_t)(((b * a.Hs + hs0) * a.Ws) * a.xpix * 2);  // modular when hs0 < 0
 #pragma unroll
         for (int s = 0; s < kMaxSlots; ++s) {
             if (s < a.sd) {
-                const int id = tid + s * NT;
-                const int row = id >> 3, nc = id & 7;
-                const uint32_t off = (dy_base + (uint32_t)row * (uint32_t)a.N + (uint32_t)nc * 8u) * 2u;
-                regs[s] = buffer_load_bf16x8(rdy, row < pvalid ? off : kOOB);
+                regs[s] = buffer_load_bf16x8(rdy, dyrel[s]);
             } else if (s < a.sd + a.sx) {
-                const int j = tid + (s - a.sd) * NT;
-                uint32_t off = kOOB;
-                if (j < a.nch_x) {
-                    const int cc = j & cpp_mask, pix = j >> a.cpp_log2;
-                    const int wr = (int)fdiv((uint32_t)pix, a.div_wcols);
-                    const int wcol = pix - wr * a.WCOLS;
-                    const int hs = hs0 + wr, ws = wcol - a.pw;
-                    if ((unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws)
-                        off = ((uint32_t)((b * a.Hs + hs) * a.Ws + ws) * (uint32_t)a.xpix + (uint32_t)(c0 + cc * 8)) * 2u;
-                }
-                regs[s] = buffer_load_bf16x8(rx, off);
+                const bool ok = xcol_ok[s] && (unsigned)(hs0 + xwr[s]) < (unsigned)a.Hs;
+                regs[s] = buffer_load_bf16x8(rx, ok ? xbase + xrel[s] : kOOB);
             }
         }
     };
@@ -149,6 +163,23 @@ __global__ __launch_bounds__(MODE == 0 ? 384 : 256, MODE == 0 ? 3 : 2) void k_wg
     const int ncolb = (wn * 32 + h16 * 16 + p * 4) * 2;
     const int ccolb = (h16 * 16 + p * 4) * 2;
     const int ksteps = a.KP >> 4;
+    // window byte offset of the two K rows this lane reads in each 16-row step: the same for every chunk
+    int xp0[kMaxKSteps], xp1[kMaxKSteps];
+#pragma unroll
+    for (int kk = 0; kk < kMaxKSteps; ++kk) {
+        const int row0 = kk * 16 + 8 * h32 + q, row1 = row0 + 4;
+        int pix0 = 0, pix1 = 0;
+        if (row0 < a.P) {
+            const int r = (int)fdiv((uint32_t)row0, a.div_wo);
+            pix0 = r * a.sh * a.WCOLS + (row0 - r * a.Wo) * a.sw;
+        }
+        if (row1 < a.P) {
+            const int r = (int)fdiv((uint32_t)row1, a.div_wo);
+            pix1 = r * a.sh * a.WCOLS + (row1 - r * a.Wo) * a.sw;
+        }
+        xp0[kk] = pix0 * a.pixb + ccolb;
+        xp1[kk] = pix1 * a.pixb + ccolb;
+    }
 
     if (chunk_begin < chunk_end) stage_load(chunk_begin);
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
@@ -156,28 +187,22 @@ __global__ __launch_bounds__(MODE == 0 ? 384 : 256, MODE == 0 ? 3 : 2) void k_wg
         stage_store();
         __syncthreads();
         if (chunk + 1 < chunk_end) stage_load(chunk + 1);  // in flight under the MFMAs below
-        for (int kk = 0; kk < ksteps; ++kk) {
-            const int row0 = kk * 16 + 8 * h32 + q, row1 = row0 + 4;
-            const bf16x8 af = tr_pair(Ys + row0 * kYPitch + ncolb, Ys + row1 * kYPitch + ncolb);
-            int pix0 = 0, pix1 = 0;
-            if (row0 < a.P) {
-                const int r = (int)fdiv((uint32_t)row0, a.div_wo);
-                pix0 = r * a.sh * a.WCOLS + (row0 - r * a.Wo) * a.sw;
-            }
-            if (row1 < a.P) {
-                const int r = (int)fdiv((uint32_t)row1, a.div_wo);
-                pix1 = r * a.sh * a.WCOLS + (row1 - r * a.Wo) * a.sw;
-            }
-            const char* xb0 = Xs + pix0 * a.pixb + ccolb;
-            const char* xb1 = Xs + pix1 * a.pixb + ccolb;
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const int t = MODE == 0 ? wt * 3 + i : wt + i * 2;
-                if (t < a.T) {
-                    // tapoff[0] = LDS bytes per window row, tapoff[1] = bytes per window pixel
-                    const int toff = MODE == 0 ? wt * a.tapoff[0] + i * a.tapoff[1] : t * a.tapoff[0];
-                    const bf16x8 bfr = tr_pair(xb0 + toff, xb1 + toff);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+        for (int kk = 0; kk < kMaxKSteps; ++kk) {
+            if (kk < ksteps) {
+                const int row0 = kk * 16 + 8 * h32 + q;
+                const bf16x8 af = tr_pair(Ys + row0 * kYPitch + ncolb, Ys + (row0 + 4) * kYPitch + ncolb);
+                const char* xb0 = Xs + xp0[kk];
+                const char* xb1 = Xs + xp1[kk];
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int t = MODE == 0 ? wt * 3 + i : wt + i * 2;
+                    if (t < a.T) {
+                        // tapoff[0] = LDS bytes per window row, tapoff[1] = bytes per window pixel
+                        const int toff = MODE == 0 ? wt * a.tapoff[0] + i * a.tapoff[1] : t * a.tapoff[0];
+                        const bf16x8 bfr = tr_pair(xb0 + toff, xb1 + toff);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -238,7 +263,7 @@ bool plan(WinGeom& g, WinArgs& a) {
     int best = 0;
     for (int R = 1; R <= g.Ho; ++R) {
         const int P = R * g.Wo, KP = ceil16(P);
-        if (KP > 112) break;
+        if (KP > kMaxKP) break;
         const int WR = (R - 1) * g.sh + g.KH;
         const int nch_x = WR * wcols * cpp;
         const int slots = (KP * 8 + nt - 1) / nt + (nch_x + nt - 1) / nt;
