@@ -327,7 +327,7 @@ def check_layernorm(M, D, time_it):
 
 # ----------------------------------------------------------------------------- others
 def check_pool():
-    for (B, C, H, W) in ((2, 64, 16, 16), (3, 64, 15, 17), (4, 64, 112, 112)):
+    for (B, C, H, W) in ((2, 64, 16, 16), (3, 64, 15, 17), (4, 64, 112, 112), (9, 64, 112, 112)):  # last: > 512 blocks (XCD grouping)
         def mp():
             x = nhwc(B, C, H, W).relu_().contiguous(memory_format=torch.channels_last)
             y, arg = native.maxpool3x3s2_fwd(x)

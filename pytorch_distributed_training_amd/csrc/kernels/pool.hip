@@ -10,18 +10,36 @@ namespace {
 
 __device__ __forceinline__ bf16x8 ld8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
+// Blocks are dealt round-robin to the 8 XCDs; windows of neighbouring output rows share input rows, so give each
+// XCD runs of 64 consecutive logical blocks (about 37 image rows of the stem pool): the shared rows are then hit in
+// that XCD's L2 instead of being fetched by two of them, while the chip still walks the tensor front to back.
+__device__ __forceinline__ uint32_t xcd_grouped_block() {
+    constexpr uint32_t GRP = 64;
+    const uint32_t bid = blockIdx.x, full = gridDim.x / (8 * GRP) * (8 * GRP);
+    if (bid >= full) return bid;
+    const uint32_t xcd = bid & 7, slot = bid >> 3;
+    return ((slot / GRP) * 8 + xcd) * GRP + slot % GRP;
+}
+
+struct PoolDiv {
+    FastDiv g, w, h;  // channel groups, width, height of the index space a thread id is decomposed over
+};
+
 __global__ __launch_bounds__(256) void k_maxpool_fwd(const bf16* __restrict__ x, bf16* __restrict__ y,
                                                      uint8_t* __restrict__ argmax, int B, int H, int W, int C, int Ho,
-                                                     int Wo) {
-    const int G = C >> 3;
-    const long total = (long)B * Ho * Wo * G;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % G);
-        long p = i / G;
-        const int wo = (int)(p % Wo);
-        p /= Wo;
-        const int ho = (int)(p % Ho);
-        const int b = (int)(p / Ho);
+                                                     int Wo, PoolDiv dv) {
+    // 32-bit indices and multiply-shift divisions: with 64-bit '/' and '%' by runtime values the index math alone
+    // cost more than the memory traffic (2.6 TB/s); the host checks that the thread count fits 31 bits
+    const uint32_t G = (uint32_t)C >> 3;
+    const uint32_t total = (uint32_t)B * Ho * Wo * G;
+    for (uint32_t i = xcd_grouped_block() * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        uint32_t p = fdiv(i, dv.g);
+        const int cg = (int)(i - p * G);
+        uint32_t t = fdiv(p, dv.w);
+        const int wo = (int)(p - t * dv.w.d);
+        const uint32_t bb = fdiv(t, dv.h);
+        const int ho = (int)(t - bb * dv.h.d);
+        const int b = (int)bb;
         float best[8];
         uint8_t arg[8];
 #pragma unroll
@@ -37,7 +55,7 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const bf16* __restrict__ x,
             for (int s = 0; s < 3; ++s) {
                 const int wi = wo * 2 - 1 + s;
                 if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
-                const bf16x8 v = ld8(x + (((long)b * H + hi) * W + wi) * C + cg * 8);
+                const bf16x8 v = ld8(x + (uint32_t)(((b * H + hi) * W + wi) * C + cg * 8));
                 const uint8_t tap = (uint8_t)(r * 3 + s);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -51,7 +69,7 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const bf16* __restrict__ x,
                 any = true;
             }
         }
-        const long off = (((long)b * Ho + ho) * Wo + wo) * C + cg * 8;
+        const uint32_t off = (uint32_t)(((b * Ho + ho) * Wo + wo) * C + cg * 8);
         bf16x8 o;
         uint64_t packed = 0;
 #pragma unroll
@@ -66,16 +84,17 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const bf16* __restrict__ x,
 
 __global__ __launch_bounds__(256) void k_maxpool_bwd(const bf16* __restrict__ dy, const uint8_t* __restrict__ argmax,
                                                      bf16* __restrict__ dx, int B, int H, int W, int C, int Ho,
-                                                     int Wo) {
-    const int G = C >> 3;
-    const long total = (long)B * H * W * G;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % G);
-        long p = i / G;
-        const int wi = (int)(p % W);
-        p /= W;
-        const int hi = (int)(p % H);
-        const int b = (int)(p / H);
+                                                     int Wo, PoolDiv dv) {
+    const uint32_t G = (uint32_t)C >> 3;
+    const uint32_t total = (uint32_t)B * H * W * G;
+    for (uint32_t i = xcd_grouped_block() * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        uint32_t p = fdiv(i, dv.g);
+        const int cg = (int)(i - p * G);
+        uint32_t t = fdiv(p, dv.w);
+        const int wi = (int)(p - t * dv.w.d);
+        const uint32_t bb = fdiv(t, dv.h);
+        const int hi = (int)(t - bb * dv.h.d);
+        const int b = (int)bb;
         float acc[8] = {0};
         // windows (ho, wo) with ho*2-1 <= hi <= ho*2+1
         const int ho_lo = (hi) / 2, ho_hi = (hi + 1) / 2;  // hi = 2ho-1+r, r in 0..2
@@ -88,7 +107,7 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const bf16* __restrict__ dy
                 if (wo < 0 || wo >= Wo) continue;
                 const int s = wi - (wo * 2 - 1);
                 if (s < 0 || s > 2) continue;
-                const long off = (((long)b * Ho + ho) * Wo + wo) * C + cg * 8;
+                const uint32_t off = (uint32_t)(((b * Ho + ho) * Wo + wo) * C + cg * 8);
                 const bf16x8 g = ld8(dy + off);
                 const uint64_t a = *reinterpret_cast<const uint64_t*>(argmax + off);
                 const uint8_t tap = (uint8_t)(r * 3 + s);
@@ -100,7 +119,7 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const bf16* __restrict__ dy
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (bf16)acc[k];
-        *reinterpret_cast<bf16x8*>(dx + (((long)b * H + hi) * W + wi) * C + cg * 8) = o;
+        *reinterpret_cast<bf16x8*>(dx + (uint32_t)(((b * H + hi) * W + wi) * C + cg * 8)) = o;
     }
 }
 
@@ -127,18 +146,19 @@ __global__ __launch_bounds__(256) void k_avgpool_fwd(const bf16* __restrict__ x,
 }
 
 __global__ __launch_bounds__(256) void k_avgpool_bwd(const bf16* __restrict__ dy, bf16* __restrict__ dx, int B, int HW,
-                                                     int C) {
-    const int G = C >> 3;
-    const long total = (long)B * HW * G;
+                                                     int C, PoolDiv dv) {
+    const uint32_t G = (uint32_t)C >> 3;
+    const uint32_t total = (uint32_t)B * HW * G;
     const float inv = 1.f / (float)HW;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % G);
-        const int b = (int)(i / ((long)HW * G));
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t p = fdiv(i, dv.g);
+        const int cg = (int)(i - p * G);
+        const int b = (int)fdiv(p, dv.w);  // dv.w divides by HW here
         const bf16x8 g = ld8(dy + (long)b * C + cg * 8);
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (bf16)((float)g[k] * inv);
-        *reinterpret_cast<bf16x8*>(dx + i * 8) = o;
+        *reinterpret_cast<bf16x8*>(dx + (long)i * 8) = o;
     }
 }
 
@@ -149,19 +169,30 @@ inline int grid_cap(long total) {
     return (int)(b < 1 ? 1 : (b > (1L << 30) ? (1L << 30) : b));
 }
 
+inline void check_index_space(long total) {
+    if (total >= (1L << 31)) {
+        fprintf(stderr, "pool: %ld work items do not fit the 31-bit index space of the kernels\n", total);
+        abort();
+    }
+}
+
 }  // namespace
 
 void launch_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int B, int H, int W, int C, int Ho, int Wo,
                              hipStream_t s) {
     const long total = (long)B * Ho * Wo * (C >> 3);
+    check_index_space(total);
+    const PoolDiv dv{make_fastdiv((uint32_t)(C >> 3)), make_fastdiv((uint32_t)Wo), make_fastdiv((uint32_t)Ho)};
     hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_cap(total)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, argmax, B, H,
-                       W, C, Ho, Wo);
+                       W, C, Ho, Wo, dv);
 }
 void launch_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int H, int W, int C, int Ho,
                              int Wo, hipStream_t s) {
     const long total = (long)B * H * W * (C >> 3);
+    check_index_space(total);
+    const PoolDiv dv{make_fastdiv((uint32_t)(C >> 3)), make_fastdiv((uint32_t)W), make_fastdiv((uint32_t)H)};
     hipLaunchKernelGGL(k_maxpool_bwd, dim3(grid_cap(total)), dim3(256), 0, s, (const bf16*)dy, argmax, (bf16*)dx, B, H,
-                       W, C, Ho, Wo);
+                       W, C, Ho, Wo, dv);
 }
 void launch_global_avgpool_fwd(const void* x, void* y, int B, int HW, int C, hipStream_t s) {
     const long total = (long)B * (C >> 3);
@@ -170,7 +201,9 @@ void launch_global_avgpool_fwd(const void* x, void* y, int B, int HW, int C, hip
 }
 void launch_global_avgpool_bwd(const void* dy, void* dx, int B, int HW, int C, hipStream_t s) {
     const long total = (long)B * HW * (C >> 3);
-    hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_cap(total)), dim3(256), 0, s, (const bf16*)dy, (bf16*)dx, B, HW, C);
+    check_index_space(total);
+    const PoolDiv dv{make_fastdiv((uint32_t)(C >> 3)), make_fastdiv((uint32_t)HW), make_fastdiv(1u)};
+    hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_cap(total)), dim3(256), 0, s, (const bf16*)dy, (bf16*)dx, B, HW, C, dv);
 }
 
 }  // namespace pdt
