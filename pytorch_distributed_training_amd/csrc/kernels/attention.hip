@@ -63,10 +63,10 @@ __device__ __forceinline__ bf16x8 acc_to_a(const f32x16& t, int blk) {
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // stage rows [0, SP) of one of q/k/v (which = 0/1/2) or of a [B,S,H,64] tensor (which < 0) into an LDS image
-template <int NT>
+template <int NT, int NW>
 __device__ __forceinline__ void stage(char* img, const bf16* src, long row_stride, int S, float scale, int tid) {
     constexpr int SP = NT * 32;
-    for (int i = tid; i < SP * 8; i += 256) {
+    for (int i = tid; i < SP * 8; i += 64 * NW) {
         const int row = i >> 3, ch = i & 7;
         bf16x8 v;
 #pragma unroll
@@ -81,8 +81,10 @@ __device__ __forceinline__ void stage(char* img, const bf16* src, long row_strid
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int NT>
-__global__ __launch_bounds__(256) void k_attn_fwd(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+// NW waves per workgroup: 4, or 8 once a head has more than 4 tiles (ViT: 7), so that every tile has its own
+// wave (one round instead of two uneven ones) and the CU holds twice the waves behind the same LDS images
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attn_fwd(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                   float* __restrict__ lse, int S, int H) {
     constexpr int SP = NT * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -92,11 +94,11 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const bf16* __restrict__ qkv, 
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const long D = (long)H * HD, rs = 3 * D;
     const bf16* base = qkv + (long)b * S * rs + h * HD;
-    stage<NT>(Ks, base + D, rs, S, 1.f, tid);
-    stage<NT>(Vs, base + 2 * D, rs, S, 1.f, tid);
+    stage<NT, NW>(Ks, base + D, rs, S, 1.f, tid);
+    stage<NT, NW>(Vs, base + 2 * D, rs, S, 1.f, tid);
     __syncthreads();
 
-    for (int qt = wave; qt < NT; qt += 4) {
+    for (int qt = wave; qt < NT; qt += NW) {
         // Q fragments straight from global (each query row is used by this wave only), scaled by 1/8
         const int q = qt * 32 + l31;
         bf16x8 bq[4];
@@ -173,8 +175,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const bf16* __restrict__ qkv, 
 }
 
 // ----------------------------------------------------------------------------------------- backward
-template <int NT>
-__global__ __launch_bounds__(256) void k_attn_bwd(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attn_bwd(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                   const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                   bf16* __restrict__ dqkv, int S, int H) {
     constexpr int SP = NT * 32;
@@ -191,10 +193,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const bf16* __restrict__ qkv, 
     const bf16* base = qkv + (long)b * S * rs + h * HD;
     const bf16* obase = out + ((long)b * S * H + h) * HD;
     const bf16* dobase = dout + ((long)b * S * H + h) * HD;
-    stage<NT>(Qs, base, rs, S, 0.125f, tid);
-    stage<NT>(Ks, base + D, rs, S, 1.f, tid);
-    stage<NT>(Vs, base + 2 * D, rs, S, 1.f, tid);
-    stage<NT>(Os, dobase, D, S, 1.f, tid);
+    stage<NT, NW>(Qs, base, rs, S, 0.125f, tid);
+    stage<NT, NW>(Ks, base + D, rs, S, 1.f, tid);
+    stage<NT, NW>(Vs, base + 2 * D, rs, S, 1.f, tid);
+    stage<NT, NW>(Os, dobase, D, S, 1.f, tid);
     if (tid < SP) {
         float d = 0.f, l = -kNegBig;
         if (tid < S) {
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const bf16* __restrict__ qkv, 
     bf16* dq_base = dqkv + (long)b * S * rs + h * HD;
 
     // ---- pass A: a wave owns a KEY tile; scores non-transposed (lane = key, regs = queries) -> dK, dV
-    for (int kt = wave; kt < NT; kt += 4) {
+    for (int kt = wave; kt < NT; kt += NW) {
         const int key = kt * 32 + l31;
         bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const bf16* __restrict__ qkv, 
     }
 
     // ---- pass B: a wave owns a QUERY tile; scores transposed (lane = query, regs = keys) -> dQ
-    for (int qt = wave; qt < NT; qt += 4) {
+    for (int qt = wave; qt < NT; qt += NW) {
         const int q = qt * 32 + l31;
         bf16x8 qf[4], gf[4];
 #pragma unroll
@@ -342,9 +344,10 @@ void launch_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, 
     const size_t lds = (size_t)2 * nt * 32 * ROWB;
 #define PDT_ATTN_FWD(N)                                                                                        \
     case N: {                                                                                                  \
-        static bool once = (set_lds(&k_attn_fwd<N>, lds), true);                                               \
+        constexpr int NW = N > 4 ? 8 : 4;                                                                      \
+        static bool once = (set_lds(&k_attn_fwd<N, NW>, lds), true);                                           \
         (void)once;                                                                                            \
-        hipLaunchKernelGGL((k_attn_fwd<N>), dim3(B * H), dim3(256), lds, s, (const bf16*)qkv, (bf16*)out, lse, S, H); \
+        hipLaunchKernelGGL((k_attn_fwd<N, NW>), dim3(B * H), dim3(64 * NW), lds, s, (const bf16*)qkv, (bf16*)out, lse, S, H); \
     } break;
     switch (nt) {
         PDT_ATTN_FWD(1) PDT_ATTN_FWD(2) PDT_ATTN_FWD(3) PDT_ATTN_FWD(4) PDT_ATTN_FWD(5) PDT_ATTN_FWD(6) PDT_ATTN_FWD(7)
@@ -360,9 +363,10 @@ void launch_attention_bwd(const void* qkv, const void* out, const void* dout, co
     const size_t lds = (size_t)4 * nt * 32 * ROWB + (size_t)2 * nt * 32 * sizeof(float);
 #define PDT_ATTN_BWD(N)                                                                                      \
     case N: {                                                                                                \
-        static bool once = (set_lds(&k_attn_bwd<N>, lds), true);                                             \
+        constexpr int NW = N > 4 ? 8 : 4;                                                                    \
+        static bool once = (set_lds(&k_attn_bwd<N, NW>, lds), true);                                         \
         (void)once;                                                                                          \
-        hipLaunchKernelGGL((k_attn_bwd<N>), dim3(B * H), dim3(256), lds, s, (const bf16*)qkv, (const bf16*)out, \
+        hipLaunchKernelGGL((k_attn_bwd<N, NW>), dim3(B * H), dim3(64 * NW), lds, s, (const bf16*)qkv, (const bf16*)out, \
                            (const bf16*)dout, lse, (bf16*)dqkv, S, H);                                       \
     } break;
     switch (nt) {
