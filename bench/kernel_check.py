@@ -165,6 +165,18 @@ def check_conv(args, time_it):
             extra["us_dgrad"] = round(timeit(lambda: native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add)), 1)
             extra["us_reduce"] = round(timeit(lambda: native.bn_bwd_reduce(dx2, act, xb, mean, invstd, True)), 1)
         record(f"conv_dgrad+bn_reduce {tag}", e < 2e-3, e, extra)
+        # gated addend (lazily masked residual gradient): same as adding the materialised masked tensor
+        gate_src = nhwc(B, C, H, W)
+        _, gmask = native.bn_apply_act(gate_src, mean * 0, invstd * 0 + 1, gamma * 0 + 1, beta * 0, None, True)
+        dx3 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add, addend_mask=gmask)
+        dx4 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, native.apply_relu_gate(add, gmask))
+        dx5, ps5 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add, (xb, act, mean, invstd), gmask)
+        ps6 = native.bn_bwd_reduce(dx4, act, xb, mean, invstd, True)
+        e2 = max(rel_err(dx3, dx4), rel_err(dx5, dx4),
+                 rel_err(native.bn_sum_partials(ps5), native.bn_sum_partials(ps6)))
+        ref_gate = (gate_src > 0)
+        e2 = max(e2, rel_err(native.apply_relu_gate(add, gmask), add * ref_gate))
+        record(f"conv_dgrad+gated_addend {tag}", e2 < 2e-3, e2, {})
 
     run_case(f"conv_fwd   {tag}", fwd)
     run_case(f"conv_dgrad {tag}", dgrad)

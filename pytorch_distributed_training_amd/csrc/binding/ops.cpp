@@ -130,15 +130,25 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
 std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_shape, int64_t KH,
                                         int64_t KW, int64_t stride, int64_t pad, const c10::optional<Tensor>& addend,
                                         const c10::optional<Tensor>& bn_x, const c10::optional<Tensor>& bn_mask,
-                                        const c10::optional<Tensor>& bn_mean, const c10::optional<Tensor>& bn_invstd) {
+                                        const c10::optional<Tensor>& bn_mean, const c10::optional<Tensor>& bn_invstd,
+                                        const c10::optional<Tensor>& addend_mask) {
     check_nhwc_bf16(dy, "dy");
     const bool bnr = bn_x.has_value() && bn_x->defined();
     const void* addend_ptr = nullptr;
+    const uint8_t* addend_mask_ptr = nullptr;
     if (addend.has_value() && addend->defined()) {
         check_nhwc_bf16(*addend, "addend");
         TORCH_CHECK(addend->sizes().vec() == x_shape, "addend must have the shape of dx");
         TORCH_CHECK(stride == 1, "addend fusion is implemented for stride-1 data gradients");
         addend_ptr = addend->data_ptr();
+        if (addend_mask.has_value() && addend_mask->defined()) {
+            TORCH_CHECK(addend_mask->is_cuda() && addend_mask->scalar_type() == at::kByte &&
+                            addend_mask->is_contiguous() && addend_mask->numel() == addend->numel() / 8,
+                        "addend_mask: expected contiguous uint8 [pixels, C/8]");
+            addend_mask_ptr = addend_mask->data_ptr<uint8_t>();
+        }
+    } else {
+        TORCH_CHECK(!(addend_mask.has_value() && addend_mask->defined()), "addend_mask without addend");
     }
     TORCH_CHECK(wt.is_cuda() && wt.scalar_type() == at::kBFloat16 && wt.dim() == 3 && wt.is_contiguous(),
                 "wt: expected contiguous bf16 [Cin][taps][Cout]");
@@ -173,6 +183,7 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
                 g.set_tap(t, (int)pad - r, (int)pad - q, t);
             }
         g.addend = addend_ptr;
+        g.addend_mask = addend_mask_ptr;
         Tensor psums, slab;
         float* slab_ptr = nullptr;
         int m_tiles = 0;
@@ -862,7 +873,8 @@ void bind_ops(pybind11::module& m) {
     m.def("conv2d_dgrad", &conv2d_dgrad, pybind11::arg("dy"), pybind11::arg("wt"), pybind11::arg("x_shape"), pybind11::arg("kh"),
           pybind11::arg("kw"), pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("addend") = pybind11::none(),
           pybind11::arg("bn_x") = pybind11::none(), pybind11::arg("bn_mask") = pybind11::none(),
-          pybind11::arg("bn_mean") = pybind11::none(), pybind11::arg("bn_invstd") = pybind11::none());
+          pybind11::arg("bn_mean") = pybind11::none(), pybind11::arg("bn_invstd") = pybind11::none(),
+          pybind11::arg("addend_mask") = pybind11::none());
     m.def("conv2d_wgrad", &conv2d_wgrad);
     m.def("conv_stem_fwd", &conv_stem_fwd);
     m.def("stem_pack_x", &stem_pack_x);

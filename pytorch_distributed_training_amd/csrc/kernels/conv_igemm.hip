@@ -379,8 +379,9 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
             bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * OPITCH + och * 16);
             if (g.addend != nullptr) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.addend) + pix * g.N + ncol);
+                const unsigned abits = g.addend_mask != nullptr ? g.addend_mask[(pix * g.N + ncol) >> 3] : 0xffu;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)a[k]);
+                for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (((abits >> k) & 1u) ? (float)a[k] : 0.f));
             }
             if (bnr) {
                 bf16x8 xv;

@@ -122,6 +122,10 @@ struct ConvGeom {
     // optional bf16 tensor with the output's shape that is added in the epilogue (fuses the residual
     // branch's gradient into the data-gradient kernel instead of a separate elementwise add)
     const void* addend;
+    // optional 1-bit-per-element gate of the addend ([pixels, N/8] bytes, the activity mask of a BN+ReLU): the
+    // epilogue adds addend where the bit is set.  Lets the residual branch hand over the UNMASKED gradient that
+    // reached the block output plus that ReLU's mask instead of materialising the masked copy.
+    const uint8_t* addend_mask;
     // elements per input pixel in memory; 0 = C (dense NHWC).  The packed stem runs with C = 32 (one filter
     // row: 8 kw slots x 4 channels, contiguous in memory) over pixels of 4 elements.
     int pix_elems;

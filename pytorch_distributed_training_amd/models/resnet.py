@@ -16,11 +16,15 @@ Each ``conv -> BN -> (+identity) -> ReLU`` group runs as the two fused nodes of
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as tnn
 
 from .. import nn as pnn
 from ..nn.functional import conv_bn_act
+
+_LAZY_RES = os.environ.get("PDT_LAZY_RES_GRAD", "1") != "0"  # A/B knob for the gated residual gradient
 
 
 def _conv3x3(cin, cout, stride=1):
@@ -50,7 +54,8 @@ class BasicBlock(tnn.Module):
         out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, return_skip=True)
         if self.downsample is not None:
             identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False)
-        return conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=identity)
+        # identity has exactly one consumer (this node): its gradient may come back ungated + mask
+        return conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=identity, lazy_residual_grad=_LAZY_RES)
 
 
 class Bottleneck(tnn.Module):
@@ -75,7 +80,7 @@ class Bottleneck(tnn.Module):
         if self.downsample is not None:
             identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False)
         out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
-        return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=identity)
+        return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=identity, lazy_residual_grad=_LAZY_RES)
 
 
 class ResNet(tnn.Module):

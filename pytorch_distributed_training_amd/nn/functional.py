@@ -43,6 +43,36 @@ def _cl(t: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------- conv
+# ---- lazily gated residual gradients --------------------------------------------------------------------------
+# The backward of ``relu(bn(y) + identity)`` owes ``identity`` the gradient ``dz * [relu active]``.  Writing that
+# tensor costs a quarter of the kernel's traffic, and its only reader is the node that produced ``identity``: a conv
+# node (which adds it inside its data-gradient epilogue) or the downsample BN (whose backward kernels know how to
+# gate with a ReLU mask anyway).  So, when the model opts in, the BN node hands back the UNGATED ``dz`` tagged with
+# the mask, and the producer applies the gate while it reads.  The producer is told at forward time to expect the
+# tag (``ctx.expect_gate``) and raises if a gradient arrives without it: a lost tag can never go unnoticed.
+_GATE_ATTR = "_pdt_relu_gate"
+_GATE_AWARE = ("_Conv2dFnBackward", "_BNActFnBackward")
+
+
+def _tag_gate(dz, mask):
+    setattr(dz, _GATE_ATTR, (mask, dz.data_ptr(), dz._version))
+    return dz
+
+
+def _take_gate(g, expected: bool):
+    """The mask ``g`` must be gated with (None: plain gradient).  Raises when a promised tag is missing/stale."""
+    tag = getattr(g, _GATE_ATTR, None) if g is not None else None
+    if tag is None:
+        if expected and g is not None:
+            raise RuntimeError("lazy residual gradient: the gradient arrived without its ReLU gate "
+                               "(the residual tensor must have exactly one consumer; pass lazy_residual_grad=False)")
+        return None
+    mask, ptr, ver = tag
+    if g.data_ptr() != ptr or g._version != ver:
+        raise RuntimeError("lazy residual gradient: tagged gradient was modified before its consumer ran")
+    return mask
+
+
 class _Conv2dFn(torch.autograd.Function):
     """``(y, stats, skip)``: ``skip`` (when requested) is the input passed through, to be used as the
     residual branch of the block.  Its gradient then arrives HERE and is added inside the data-gradient
@@ -77,15 +107,18 @@ class _Conv2dFn(torch.autograd.Function):
         x, wk = ctx.saved_tensors
         be, stride, padding, w_shape, w_dtype, x_shape = ctx.cfg
         dx = dw = None
+        gate = _take_gate(dskip, getattr(ctx, "expect_gate", False))
         if dy is None:
-            return dskip, None, None, None, None, None, None
+            return (dskip if gate is None else be.apply_relu_gate(_cl(dskip), gate)), None, None, None, None, None, None
         dy = _cl(dy)
         if ctx.needs_input_grad[0]:
             sink = ctx.bn_sink
             dskip = None if dskip is None else _cl(dskip)
             if sink is not None:
-                dx, psums = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, dskip, sink.operands())
+                dx, psums = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, dskip, sink.operands(), gate)
                 sink.fulfil(dx, psums)
+            elif gate is not None:
+                dx = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, dskip, addend_mask=gate)
             else:
                 dx = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, dskip)
         if ctx.needs_input_grad[1]:
@@ -102,6 +135,8 @@ def conv2d(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = Fals
     if w_lp is not None and w_lp.dtype != x.dtype:
         w_lp = None
     y, stats, skip = _Conv2dFn.apply(x, weight, w_lp, int(stride), int(padding), bool(want_stats), bool(with_skip))
+    if with_skip and skip is not None:
+        skip._pdt_lazy_grad_ok = int(stride) == 1  # the masked-addend epilogue exists for stride-1 data gradients
     return (y, stats, skip) if with_skip else (y, stats)
 
 
@@ -161,7 +196,7 @@ class _BNSink:
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, stats, cfg: BNConfig, relu: bool, sink=None):
+    def forward(ctx, x, gamma, beta, residual, stats, cfg: BNConfig, relu: bool, sink=None, lazy_res: bool = False):
         be = backend_for(x)
         x = _cl(x)
         if residual is not None:
@@ -204,6 +239,7 @@ class _BNActFn(torch.autograd.Function):
         if sink is not None and relu and be is not reference and act is not None and act.dtype == torch.uint8:
             sink.arm(x, act, mean, invstd)
             ctx.sink = sink
+        ctx.lazy_res = bool(lazy_res and relu and residual is not None and act is not None)
         ctx.save_for_backward(x, act if relu else None, mean, invstd, g32, count_t)
         ctx.cfg = (be, cfg, relu, world, count, residual is not None,
                    None if gamma is None else gamma.dtype, None if beta is None else beta.dtype)
@@ -214,10 +250,18 @@ class _BNActFn(torch.autograd.Function):
         x, z, mean, invstd, g32, count_t = ctx.saved_tensors
         be, cfg, relu, world, count, has_res, gdt, bdt = ctx.cfg
         psums = ctx.sink.take(dz) if ctx.sink is not None else None  # reduced by the consumer conv's dgrad epilogue
+        gate = _take_gate(dz, getattr(ctx, "expect_gate", False))
         dz = _cl(dz)
+        if gate is not None:
+            if relu:  # (not produced by the models here: a gated gradient into a BN that has its own ReLU)
+                dz = be.apply_relu_gate(dz, gate)
+            else:     # downsample BN: the block output's ReLU gates its gradient; the kernels take a mask anyway
+                relu, z = True, gate
         if psums is None:
             psums = be.bn_bwd_reduce(dz, z, x, mean, invstd, relu)  # local partial rows [P, 2, C]
-        want_dres = has_res and ctx.needs_input_grad[3]
+        want_res = has_res and ctx.needs_input_grad[3]
+        lazy = want_res and ctx.lazy_res and gate is None
+        want_dres = want_res and not lazy
         if cfg.training and world > 1:
             # the affine grads stay local (DDP averages them); the sums that feed grad_input are global
             sums = be.bn_sum_partials(psums)
@@ -235,20 +279,35 @@ class _BNActFn(torch.autograd.Function):
         dbeta = sums[0].to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
         if not ctx.needs_input_grad[0]:
             dx = None
-        return dx, dgamma, dbeta, dres, None, None, None, None
+        if lazy:
+            dres = _tag_gate(dz, z)  # ungated gradient + this node's ReLU mask: the producer of the residual gates it
+        return dx, dgamma, dbeta, dres, None, None, None, None, None
 
 
 _FUSE_BN_REDUCE = os.environ.get("PDT_FUSE_BN_REDUCE", "1") != "0"
 
 
-def bn_act(x, gamma, beta, cfg: BNConfig, residual=None, relu: bool = False, stats=None):
+def bn_act(x, gamma, beta, cfg: BNConfig, residual=None, relu: bool = False, stats=None,
+           lazy_residual_grad: bool = False):
+    """``lazy_residual_grad=True`` (model opt-in; requires that ``residual`` has NO other consumer): the gradient of
+    ``residual`` is handed to its producer ungated together with this node's ReLU mask, see ``_tag_gate``."""
+    lazy = False
+    if lazy_residual_grad and relu and residual is not None and torch.is_grad_enabled() and residual.requires_grad:
+        prod = residual.grad_fn
+        if prod is not None and type(prod).__name__ in _GATE_AWARE and getattr(residual, "_pdt_lazy_grad_ok", False):
+            lazy = True
     if relu and _FUSE_BN_REDUCE and x.is_cuda and torch.is_grad_enabled():
         sink = _BNSink()
-        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, True, sink)
+        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, True, sink, lazy)
         if sink.x is not None:
             z._pdt_bn_sink = sink  # picked up by the conv node that consumes z
-        return z
-    return _BNActFn.apply(x, gamma, beta, residual, stats, cfg, bool(relu))
+    else:
+        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, bool(relu), None, lazy)
+    if lazy and z.grad_fn is not None and getattr(z.grad_fn, "lazy_res", False):
+        residual.grad_fn.expect_gate = True  # a gradient without its gate is now an error, not a wrong result
+    if not relu and z.requires_grad:
+        z._pdt_lazy_grad_ok = True  # a BN without ReLU can take a gated gradient (its kernels accept a mask)
+    return z
 
 
 # ---------------------------------------------------------------- attention
@@ -378,7 +437,8 @@ def softmax_cross_entropy(logits, labels):
 
 
 # ------------------------------------------------------------------ helpers
-def conv_bn_act(x, conv, bn, relu: bool = True, residual=None, return_skip: bool = False):
+def conv_bn_act(x, conv, bn, relu: bool = True, residual=None, return_skip: bool = False,
+                lazy_residual_grad: bool = False):
     """``act(bn(conv(x)) [+ residual])`` through the fused nodes.
 
     ``conv``/``bn`` are modules (parameter containers); bias-free square convs with dilation 1 and
@@ -419,4 +479,4 @@ def conv_bn_act(x, conv, bn, relu: bool = True, residual=None, return_skip: bool
         y, stats, skip = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats, with_skip=True)
     else:
         y, stats = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats)
-    return done(bn(y, residual=residual, relu=relu, stats=stats), skip)
+    return done(bn(y, residual=residual, relu=relu, stats=stats, lazy_residual_grad=lazy_residual_grad), skip)

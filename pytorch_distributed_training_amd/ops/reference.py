@@ -23,9 +23,20 @@ def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False, return
     return (y, stats, x) if return_saved else (y, stats)
 
 
-def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None):
+def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None, addend_mask=None):
+    """``addend_mask``: activity "mask" of a BN+ReLU as this backend keeps it (the post-ReLU output itself);
+    the addend only counts where that ReLU was active."""
     dx = _conv2d_dgrad(dy, w, x_shape, stride, padding)
-    return dx if addend is None else dx + addend
+    if addend is None:
+        return dx
+    if addend_mask is not None:
+        addend = addend * (addend_mask > 0).to(addend.dtype)
+    return dx + addend
+
+
+def apply_relu_gate(g, mask):
+    """``g`` where the ReLU that produced ``mask`` was active, 0 elsewhere."""
+    return g * (mask > 0).to(g.dtype)
 
 
 def _conv2d_dgrad(dy, w, x_shape, stride: int, padding: int):

@@ -345,3 +345,48 @@ def test_attention_function_matches_torch_autograd():
     ref.backward(dy)
     assert torch.allclose(out, ref, rtol=1e-4, atol=1e-5)
     assert torch.allclose(g, qkv.grad, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ lazily gated residual gradient
+@pytest.mark.parametrize("name", ["resnet18", "resnet50"])
+def test_lazy_residual_grad_matches_materialised(name, monkeypatch):
+    """The block-output BN hands the residual's producer the UNGATED gradient + its ReLU mask
+    (functional._tag_gate); gradients must equal the path that writes the gated tensor
+    (reference semantics: /root/reference/main.py:100-103, autograd of relu(bn(y) + identity))."""
+    import pytorch_distributed_training_amd.models.resnet as R
+    import pytorch_distributed_training_amd.nn.functional as F
+
+    def grads(lazy):
+        monkeypatch.setattr(R, "_LAZY_RES", lazy)
+        tags = []
+        orig = F._tag_gate
+        monkeypatch.setattr(F, "_tag_gate", lambda dz, m: (tags.append(1), orig(dz, m))[1])
+        torch.manual_seed(0)
+        from pytorch_distributed_training_amd.models import build_model
+        m = build_model(name, 10)
+        x = torch.randn(2, 3, 32, 32, requires_grad=True)
+        m(x).square().sum().backward()
+        return len(tags), x.grad.clone(), [p.grad.clone() for p in m.parameters()]
+
+    n1, gx1, gp1 = grads(True)
+    n0, gx0, gp0 = grads(False)
+    assert n1 == {"resnet18": 8, "resnet50": 16}[name] and n0 == 0
+    assert torch.equal(gx1, gx0)
+    for a, b in zip(gp1, gp0):
+        assert torch.equal(a, b)
+
+
+def test_lazy_residual_grad_refuses_second_consumer():
+    """A residual with two consumers would receive an ungated gradient through autograd's sum: the producer was
+    told to expect the gate and must raise instead of training on a wrong gradient."""
+    import pytorch_distributed_training_amd.nn as pnn
+    from pytorch_distributed_training_amd.nn.functional import conv_bn_act
+
+    torch.manual_seed(0)
+    c1, b1 = pnn.Conv2d(8, 8, 1, bias=False), pnn.BatchNorm2d(8)
+    c2, b2 = pnn.Conv2d(8, 8, 3, padding=1, bias=False), pnn.BatchNorm2d(8)
+    x = torch.randn(2, 8, 6, 6, requires_grad=True)
+    out, skip = conv_bn_act(x, c1, b1, relu=True, return_skip=True)
+    z = conv_bn_act(out, c2, b2, relu=True, residual=skip, lazy_residual_grad=True)
+    with pytest.raises(RuntimeError, match="lazy residual gradient"):
+        (z.sum() + skip.sum()).backward()
