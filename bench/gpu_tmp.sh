@@ -1,0 +1,6 @@
+set -e
+timeout -k 10 300 python -u bench/kernel_check.py --only bn | tail -3
+timeout -k 10 600 python -u -m pytest tests/test_gpu.py -x -q --timeout 120 --timeout-method thread 2>&1 | tail -3
+timeout -k 10 300 python bench.py --steps 20 --warmup 5
+PDT_DEFER_DS_BN=0 timeout -k 10 300 python bench.py --steps 20 --warmup 5
+timeout -k 10 300 python bench.py --steps 30 --warmup 8 --batch_size 256

@@ -260,6 +260,12 @@ def check_bn(B, C, H, W, time_it):
                 us = timeit(lambda: native.bn_apply_act(x, mr, ir, gamma, beta, res, True))
                 extra = {"us": round(us, 1), "GBps": round(3 * x.numel() * 2 / us / 1e3, 1)}
             record(f"bn_apply r{int(relu)} res{int(use_res)} {tag}", e < 1e-2, e, extra)
+        # residual that is the un-normalised input of another BN (deferred downsample BN)
+        ra = (torch.randn(C, device=DEV) * 0.2, torch.rand(C, device=DEV) + 0.5, torch.rand(C, device=DEV) + 0.5,
+              torch.randn(C, device=DEV) * 0.1)
+        z, _ = native.bn_apply_act(x, mr, ir, gamma, beta, res, True, ra)
+        zr, _ = reference.bn_apply_act(x, mr, ir, gamma, beta, res, True, ra)
+        record(f"bn_apply+res_affine {tag}", rel_err(z, zr) < 1e-2, rel_err(z, zr))
 
     def bwd():
         st = reference.bn_stats(x)

@@ -458,7 +458,8 @@ Tensor bn_sum_partials(const Tensor& stats) {
 // -> (z, mask): mask is the 1-bit-per-element ReLU activity map [M, C/8] uint8 (undefined without relu);
 // the backward kernels read it instead of the 16x larger z
 std::tuple<Tensor, Tensor> bn_apply_act(const Tensor& x, const Tensor& mean, const Tensor& invstd, const Tensor& gamma,
-                                        const Tensor& beta, const c10::optional<Tensor>& residual, bool relu) {
+                                        const Tensor& beta, const c10::optional<Tensor>& residual, bool relu,
+                                        const c10::optional<std::vector<Tensor>>& res_affine) {
     check_nhwc_bf16(x, "x");
     const long C = x.size(1), M = x.numel() / C;
     TORCH_CHECK(bn_channels_ok(C), "bn: unsupported channel count ", C);
@@ -473,9 +474,16 @@ std::tuple<Tensor, Tensor> bn_apply_act(const Tensor& x, const Tensor& mean, con
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor z = at::empty_like(x), mask;
     if (relu) mask = at::empty({M, C / 8}, x.options().dtype(at::kByte));
+    BnAffine ra{nullptr, nullptr, nullptr, nullptr};
+    if (res_affine.has_value()) {  // the residual is the INPUT of a ReLU-less BN whose affine is applied here
+        TORCH_CHECK(res != nullptr && res_affine->size() == 4, "res_affine: (mean, invstd, gamma, beta) of the residual");
+        for (const auto& t : *res_affine) check_vec_f32(t, C, "res_affine");
+        ra = BnAffine{(*res_affine)[0].data_ptr<float>(), (*res_affine)[1].data_ptr<float>(),
+                      (*res_affine)[2].data_ptr<float>(), (*res_affine)[3].data_ptr<float>()};
+    }
     launch_bn_apply(x.data_ptr(), res, z.data_ptr(), relu ? mask.data_ptr<uint8_t>() : nullptr, M, (int)C,
                     mean.data_ptr<float>(), invstd.data_ptr<float>(), gamma.data_ptr<float>(), beta.data_ptr<float>(),
-                    relu ? 1 : 0, cur_stream(x));
+                    relu ? 1 : 0, ra, cur_stream(x));
     return {z, mask};
 }
 
@@ -884,7 +892,9 @@ void bind_ops(pybind11::module& m) {
     m.def("bn_stats", &bn_stats);
     m.def("bn_finalize", &bn_finalize);
     m.def("bn_sum_partials", &bn_sum_partials);
-    m.def("bn_apply_act", &bn_apply_act);
+    m.def("bn_apply_act", &bn_apply_act, pybind11::arg("x"), pybind11::arg("mean"), pybind11::arg("invstd"),
+          pybind11::arg("gamma"), pybind11::arg("beta"), pybind11::arg("residual"), pybind11::arg("relu"),
+          pybind11::arg("res_affine") = pybind11::none());
     m.def("bn_bwd_reduce", &bn_bwd_reduce);
     m.def("bn_bwd_elemt", &bn_bwd_elemt);
     m.def("attention_fwd", &attention_fwd);

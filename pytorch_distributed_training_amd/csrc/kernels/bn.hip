@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ 
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta) {
+                                                       const float* __restrict__ beta, BnAffine ra) {
     const Map m = make_map(C);
     float a[8], b[8];
     {
@@ -165,6 +165,22 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ 
         for (int k = 0; k < 8; ++k) {
             a[k] = is[k] * ga[k];
             b[k] = be[k] - mu[k] * a[k];
+        }
+    }
+    // residual that is itself the INPUT of a (ReLU-less) BatchNorm, e.g. the downsample branch: its affine is
+    // applied here, so that BN never writes its output tensor (one write + one read of a block output saved)
+    float ra_s[8];
+    const bool res_affine = RES && ra.mean != nullptr;
+    if (res_affine) {
+        float mu[8], is[8], ga[8], be[8];
+        ld8f(ra.mean + m.cg * 8, mu);
+        ld8f(ra.invstd + m.cg * 8, is);
+        ld8f(ra.gamma + m.cg * 8, ga);
+        ld8f(ra.beta + m.cg * 8, be);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            ra_s[k] = is[k] * ga[k];
+            b[k] += be[k] - mu[k] * ra_s[k];  // both shifts folded into one
         }
     }
     // grid-stride rows (the whole grid walks memory front to back), kUnroll rows per trip with all their loads
@@ -192,8 +208,13 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ 
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = (float)v[u][k] * a[k] + b[k];
             if (RES) {
+                if (res_affine) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] += (float)rv[u][k];
+                    for (int k = 0; k < 8; ++k) o[k] += (float)rv[u][k] * ra_s[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] += (float)rv[u][k];
+                }
             }
             if (RELU) {
                 unsigned bits = 0;
@@ -412,13 +433,14 @@ void launch_bn_finalize(const float* stats, int nparts, int C, float count, cons
 }
 
 void launch_bn_apply(const void* x, const void* residual, void* z, uint8_t* mask, long M, int C, const float* mean,
-                     const float* invstd, const float* gamma, const float* beta, int relu, hipStream_t s) {
+                     const float* invstd, const float* gamma, const float* beta, int relu, const BnAffine& res_affine,
+                     hipStream_t s) {
     const int R = kThreads / (C >> 3);
     const long blocks = stream_blocks(M, R, 0);
     dim3 grid((int)blocks), block(kThreads);
 #define PDT_APPLY(RELU, RES)                                                                                    \
     hipLaunchKernelGGL((k_bn_apply<RELU, RES>), grid, block, 0, s, (const bf16*)x, (const bf16*)residual, (bf16*)z, \
-                       mask, M, C, mean, invstd, gamma, beta)
+                       mask, M, C, mean, invstd, gamma, beta, res_affine)
     if (relu && residual) PDT_APPLY(true, true);
     else if (relu) PDT_APPLY(true, false);
     else if (residual) PDT_APPLY(false, true);

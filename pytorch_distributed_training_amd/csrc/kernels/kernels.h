@@ -68,8 +68,16 @@ void launch_bn_finalize(const float* stats, int nparts, int C, float count, cons
                         float momentum, float* running_mean, float* running_var, long* num_batches_tracked,
                         float* mean, float* invstd, float* sums_out, hipStream_t s);
 // relu: also writes the 1-bit-per-element activity mask [M][C/8] that the backward kernels take as `z`
-void launch_bn_apply(const void* x, const void* residual, void* z, uint8_t* mask, long M, int C, const float* mean,
-                     const float* invstd, const float* gamma, const float* beta, int relu, hipStream_t s);
+// per-channel BatchNorm coefficients of a tensor that enters another kernel un-normalised (all null: none)
+struct BnAffine {
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+};
+void launch_bn_apply(const void* x, const void* residual, void* z, uint8_t* mask /*[M][C/8] or null*/, long M, int C,
+                     const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                     const BnAffine& res_affine, hipStream_t s);
 void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, int C, const float* mean,
                           const float* invstd, int relu, float* slab /*[parts][2][C]*/, int parts,
                           hipStream_t s);

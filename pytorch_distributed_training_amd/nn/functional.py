@@ -194,9 +194,24 @@ class _BNSink:
         return ps if ok else None
 
 
+class _PendingAffine:
+    """A ReLU-less BN whose ONLY consumer is the residual input of another BN node (the downsample branch) does not
+    have to write its output: it returns its input untouched together with this holder, and the consumer applies
+    ``(mean, invstd, gamma, beta)`` while it reads the tensor (``bn_apply_act(..., res_affine=...)``).  The backward
+    of the deferring node is unchanged: the gradient w.r.t. its (virtual) output is what the consumer returns for
+    its residual.  ``consumed`` is checked in that backward: an un-normalised tensor that went anywhere else is an
+    error, not a silently wrong activation."""
+
+    __slots__ = ("operands", "consumed")
+
+    def __init__(self):
+        self.operands, self.consumed = None, False
+
+
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, stats, cfg: BNConfig, relu: bool, sink=None, lazy_res: bool = False):
+    def forward(ctx, x, gamma, beta, residual, stats, cfg: BNConfig, relu: bool, sink=None, lazy_res: bool = False,
+                defer=None, res_affine=None):
         be = backend_for(x)
         x = _cl(x)
         if residual is not None:
@@ -234,7 +249,14 @@ class _BNActFn(torch.autograd.Function):
             invstd = torch.rsqrt(cfg.running_var.float() + cfg.eps)
         g32 = gamma.float() if gamma is not None else torch.ones(c, device=x.device)
         b32 = beta.float() if beta is not None else torch.zeros(c, device=x.device)
-        z, act = be.bn_apply_act(x, mean, invstd, g32, b32, residual, relu)
+        ctx.defer = defer
+        if defer is not None:  # (relu False, no residual: checked by bn_act) the consumer applies the affine
+            defer.operands = (mean, invstd, g32, b32)
+            z, act = x.view_as(x), None
+        elif res_affine is not None:
+            z, act = be.bn_apply_act(x, mean, invstd, g32, b32, residual, relu, res_affine)
+        else:
+            z, act = be.bn_apply_act(x, mean, invstd, g32, b32, residual, relu)
         ctx.sink = None
         if sink is not None and relu and be is not reference and act is not None and act.dtype == torch.uint8:
             sink.arm(x, act, mean, invstd)
@@ -249,6 +271,9 @@ class _BNActFn(torch.autograd.Function):
     def backward(ctx, dz):
         x, z, mean, invstd, g32, count_t = ctx.saved_tensors
         be, cfg, relu, world, count, has_res, gdt, bdt = ctx.cfg
+        if ctx.defer is not None and not ctx.defer.consumed:
+            raise RuntimeError("deferred BatchNorm apply: the un-normalised output was not consumed as the residual "
+                               "of a fused BN node (pass defer_apply=False)")
         psums = ctx.sink.take(dz) if ctx.sink is not None else None  # reduced by the consumer conv's dgrad epilogue
         gate = _take_gate(dz, getattr(ctx, "expect_gate", False))
         dz = _cl(dz)
@@ -281,16 +306,28 @@ class _BNActFn(torch.autograd.Function):
             dx = None
         if lazy:
             dres = _tag_gate(dz, z)  # ungated gradient + this node's ReLU mask: the producer of the residual gates it
-        return dx, dgamma, dbeta, dres, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 _FUSE_BN_REDUCE = os.environ.get("PDT_FUSE_BN_REDUCE", "1") != "0"
 
 
 def bn_act(x, gamma, beta, cfg: BNConfig, residual=None, relu: bool = False, stats=None,
-           lazy_residual_grad: bool = False):
+           lazy_residual_grad: bool = False, defer_apply: bool = False):
     """``lazy_residual_grad=True`` (model opt-in; requires that ``residual`` has NO other consumer): the gradient of
     ``residual`` is handed to its producer ungated together with this node's ReLU mask, see ``_tag_gate``."""
+    if defer_apply and not relu and residual is None:
+        # the caller promises that the result only feeds the ``residual`` of another bn_act (see _PendingAffine)
+        pend = _PendingAffine()
+        z = _BNActFn.apply(x, gamma, beta, None, stats, cfg, False, None, False, pend)
+        z._pdt_pending_affine = pend
+        if z.requires_grad:
+            z._pdt_lazy_grad_ok = True
+        return z
+    res_affine = None
+    pend = getattr(residual, "_pdt_pending_affine", None) if residual is not None else None
+    if pend is not None:
+        res_affine, pend.consumed = pend.operands, True
     lazy = False
     if lazy_residual_grad and relu and residual is not None and torch.is_grad_enabled() and residual.requires_grad:
         prod = residual.grad_fn
@@ -298,11 +335,11 @@ def bn_act(x, gamma, beta, cfg: BNConfig, residual=None, relu: bool = False, sta
             lazy = True
     if relu and _FUSE_BN_REDUCE and x.is_cuda and torch.is_grad_enabled():
         sink = _BNSink()
-        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, True, sink, lazy)
+        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, True, sink, lazy, None, res_affine)
         if sink.x is not None:
             z._pdt_bn_sink = sink  # picked up by the conv node that consumes z
     else:
-        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, bool(relu), None, lazy)
+        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, bool(relu), None, lazy, None, res_affine)
     if lazy and z.grad_fn is not None and getattr(z.grad_fn, "lazy_res", False):
         residual.grad_fn.expect_gate = True  # a gradient without its gate is now an error, not a wrong result
     if not relu and z.requires_grad:
@@ -438,7 +475,7 @@ def softmax_cross_entropy(logits, labels):
 
 # ------------------------------------------------------------------ helpers
 def conv_bn_act(x, conv, bn, relu: bool = True, residual=None, return_skip: bool = False,
-                lazy_residual_grad: bool = False):
+                lazy_residual_grad: bool = False, defer_apply: bool = False):
     """``act(bn(conv(x)) [+ residual])`` through the fused nodes.
 
     ``conv``/``bn`` are modules (parameter containers); bias-free square convs with dilation 1 and
@@ -479,4 +516,5 @@ def conv_bn_act(x, conv, bn, relu: bool = True, residual=None, return_skip: bool
         y, stats, skip = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats, with_skip=True)
     else:
         y, stats = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats)
-    return done(bn(y, residual=residual, relu=relu, stats=stats, lazy_residual_grad=lazy_residual_grad), skip)
+    return done(bn(y, residual=residual, relu=relu, stats=stats, lazy_residual_grad=lazy_residual_grad,
+                   defer_apply=defer_apply), skip)

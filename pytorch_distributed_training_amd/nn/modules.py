@@ -88,14 +88,15 @@ class BatchNorm2d(tnn.BatchNorm2d):
                           self.momentum, self.eps, use_batch, sync=self._sync and self.training,
                           group=self.process_group)
 
-    def forward(self, x, residual=None, relu: bool = False, stats=None, lazy_residual_grad: bool = False):
+    def forward(self, x, residual=None, relu: bool = False, stats=None, lazy_residual_grad: bool = False,
+                defer_apply: bool = False):
         if x.dim() != 4:
             raise ValueError(f"expected 4D input (got {x.dim()}D input)")
         cfg = self._cfg()
         if not cfg.training:
             stats = None
         return F.bn_act(x, self.weight, self.bias, cfg, residual=residual, relu=relu, stats=stats,
-                        lazy_residual_grad=lazy_residual_grad)
+                        lazy_residual_grad=lazy_residual_grad, defer_apply=defer_apply)
 
 
 class SyncBatchNorm(BatchNorm2d):

@@ -167,9 +167,12 @@ def bn_finalize(stats, count, eps: float, running_mean=None, running_var=None, m
     return _C.bn_finalize(stats.contiguous(), c, cd, eps, momentum, running_mean, running_var, num_batches_tracked)
 
 
-def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False):
-    """-> (z, act): ``act`` is the uint8 [M, C/8] ReLU bitmask the backward kernels read (None without relu)"""
-    return _C.bn_apply_act(x, mean, invstd, gamma.contiguous(), beta.contiguous(), residual, relu)
+def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False, res_affine=None):
+    """-> (z, act): ``act`` is the uint8 [M, C/8] ReLU bitmask the backward kernels read (None without relu).
+    ``res_affine = (mean, invstd, gamma, beta)``: ``residual`` is the un-normalised input of another (ReLU-less)
+    BatchNorm whose affine the kernel applies while it reads it."""
+    ra = None if res_affine is None else [t.contiguous() for t in res_affine]
+    return _C.bn_apply_act(x, mean, invstd, gamma.contiguous(), beta.contiguous(), residual, relu, ra)
 
 
 def bn_bwd_reduce(dz, z, x, mean, invstd, relu: bool):

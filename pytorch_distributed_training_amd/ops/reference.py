@@ -86,7 +86,7 @@ def bn_finalize(stats, count, eps: float, running_mean=None, running_var=None, m
     return mean, invstd
 
 
-def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False):
+def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False, res_affine=None):
     """``z = act((x-mean)*invstd*gamma + beta [+ residual])`` in the input dtype -> ``(z, act)`` where
     ``act`` is what the backward ops take to gate the ReLU (here ``z`` itself; the HIP path hands out a
     1-bit-per-element mask instead)."""
@@ -94,7 +94,11 @@ def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False
     b = (beta - mean * invstd * gamma).view(1, -1, 1, 1)
     z = x.float() * a + b
     if residual is not None:
-        z = z + residual.float()
+        r = residual.float()
+        if res_affine is not None:  # the residual is the input of a ReLU-less BN: apply that BN's affine here
+            rm, ri, rg, rb = res_affine
+            r = r * (ri * rg).view(1, -1, 1, 1) + (rb - rm * ri * rg).view(1, -1, 1, 1)
+        z = z + r
     if relu:
         z = z.clamp_min_(0.0)
     z = z.to(x.dtype)
