@@ -368,6 +368,28 @@ def check_pool():
         run_case("avgpool", ap)
 
 
+def check_stem_tail(B, C, H, W, time_it):
+    """fused maxpool(relu(bn(u))) forward against the unfused native kernels (bn_apply_act -> maxpool): pooled
+    values, winning taps and the ReLU mask must be IDENTICAL"""
+    tag = f"B{B} C{C} {H}x{W}"
+
+    def run():
+        u = (nhwc(B, C, H, W) * 1.5 + 0.2).contiguous(memory_format=torch.channels_last)
+        gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3
+        mean, invstd = reference.bn_finalize(reference.bn_stats(u), float(B * H * W), 1e-5)
+        y, arg, mask = native.bn_relu_maxpool_fwd(u, mean, invstd, gamma, beta)
+        z, act = native.bn_apply_act(u, mean, invstd, gamma, beta, None, True)
+        y2, arg2 = native.maxpool3x3s2_fwd(z)
+        e = float((y.float() != y2.float()).sum()) + float((arg != arg2).sum()) + float((mask != act).sum())
+        extra = {}
+        if time_it:
+            extra["us_fused"] = round(timeit(lambda: native.bn_relu_maxpool_fwd(u, mean, invstd, gamma, beta)), 1)
+            extra["us_unfused"] = round(timeit(lambda: native.maxpool3x3s2_fwd(
+                native.bn_apply_act(u, mean, invstd, gamma, beta, None, True)[0])), 1)
+        record(f"bn_relu_maxpool {tag}", e == 0, e, extra)
+    run_case(f"bn_relu_maxpool {tag}", run)
+
+
 def check_loss(time_it):
     for (B, N, dt) in ((256, 1000, torch.bfloat16), (33, 1000, torch.float32), (7, 10, torch.bfloat16), (5, 3001, torch.float32)):
         def ce():
@@ -449,6 +471,9 @@ def main():
         check_optim(a.time)
         check_loss(a.time)
         check_pool()
+    if only is None or "stemtail" in only or "bn" in only:
+        for shp in ((2, 64, 16, 16), (3, 64, 15, 17), (2, 128, 9, 9)) + (() if a.quick else ((128, 64, 112, 112),)):
+            check_stem_tail(*shp, a.time)
     if only is None or "bn" in only:
         shapes = [(4, 64, 8, 8), (3, 256, 7, 5), (2, 2048, 3, 3), (5, 128, 9, 9)]
         if not a.quick:

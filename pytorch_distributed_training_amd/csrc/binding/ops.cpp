@@ -649,6 +649,25 @@ Tensor maxpool3x3s2_bwd(const Tensor& dy, const Tensor& arg, std::vector<int64_t
     launch_maxpool3x3s2_bwd(dy.data_ptr(), arg.data_ptr<uint8_t>(), dx.data_ptr(), B, H, W, C, Ho, Wo, cur_stream(dy));
     return dx;
 }
+// ---- stem tail fused: maxpool3x3/2/1(relu(bn(u))) --------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor> bn_relu_maxpool_fwd(const Tensor& u, const Tensor& mean, const Tensor& invstd,
+                                               const Tensor& gamma, const Tensor& beta) {
+    check_nhwc_bf16(u, "u");
+    const long B = u.size(0), C = u.size(1), H = u.size(2), W = u.size(3);
+    TORCH_CHECK(bn_channels_ok(C), "bn_relu_maxpool: unsupported channel count ", C);
+    check_vec_f32(mean, C, "mean"); check_vec_f32(invstd, C, "invstd");
+    check_vec_f32(gamma, C, "gamma"); check_vec_f32(beta, C, "beta");
+    const long Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(u.device());
+    Tensor y = empty_nhwc(B, C, Ho, Wo, u);
+    Tensor arg = at::empty({B, Ho, Wo, C}, u.options().dtype(at::kByte));
+    Tensor mask = at::empty({B * H * W, C / 8}, u.options().dtype(at::kByte));
+    launch_bn_relu_maxpool_fwd(u.data_ptr(), y.data_ptr(), arg.data_ptr<uint8_t>(), mask.data_ptr<uint8_t>(), B, H, W, C, Ho, Wo,
+                               mean.data_ptr<float>(), invstd.data_ptr<float>(), gamma.data_ptr<float>(),
+                               beta.data_ptr<float>(), cur_stream(u));
+    return {y, arg, mask};
+}
+
 Tensor global_avgpool_fwd(const Tensor& x) {
     check_nhwc_bf16(x, "x");
     const long B = x.size(0), C = x.size(1), HW = x.size(2) * x.size(3);
@@ -903,6 +922,7 @@ void bind_ops(pybind11::module& m) {
     m.def("layernorm_bwd", &layernorm_bwd);
     m.def("maxpool3x3s2_fwd", &maxpool3x3s2_fwd);
     m.def("maxpool3x3s2_bwd", &maxpool3x3s2_bwd);
+    m.def("bn_relu_maxpool_fwd", &bn_relu_maxpool_fwd);
     m.def("global_avgpool_fwd", &global_avgpool_fwd);
     m.def("global_avgpool_bwd", &global_avgpool_bwd);
     m.def("softmax_ce", &softmax_ce);

@@ -408,6 +408,96 @@ long stream_blocks(long M, int R, long cap) {
     return blocks < 1 ? 1 : blocks;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Stem tail fused: y = maxpool3x3/2/1(relu(bn(u))).  The full-resolution activation relu(bn(u)) is never
+// written: the forward reads the conv output u once and writes the pooled tensor, the winning tap per element
+// and the 1-bit ReLU mask of the full-resolution pixels (each window owns the 2x2 pixels at its taps (1..2, 1..2),
+// which tile the image exactly once).  The backward is the unfused one (pool backward, then the BN kernels with
+// the mask): a variant that gathered the pooled gradient inside the BN reduce / grad-input kernels measured
+// 1.7x SLOWER than those three streaming passes (the gather ran twice), so it was dropped.
+struct PoolGeom {
+    int B, H, W, C, Ho, Wo;
+    FastDiv dw, dh;  // forward: divide by Wo, Ho; backward: by W, H
+};
+
+__device__ __forceinline__ void bn_coeffs(const Map& m, const float* mean, const float* invstd, const float* gamma,
+                                          const float* beta, float (&a)[8], float (&b)[8]) {
+    float mu[8], is[8], ga[8], be[8];
+    ld8f(mean + m.cg * 8, mu);
+    ld8f(invstd + m.cg * 8, is);
+    ld8f(gamma + m.cg * 8, ga);
+    ld8f(beta + m.cg * 8, be);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = is[k] * ga[k];
+        b[k] = be[k] - mu[k] * a[k];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_relu_maxpool_fwd(const bf16* __restrict__ u, bf16* __restrict__ y,
+                                                                 uint8_t* __restrict__ argmax,
+                                                                 uint8_t* __restrict__ mask, PoolGeom g,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta) {
+    const Map m = make_map(g.C);
+    float a[8], b[8];
+    bn_coeffs(m, mean, invstd, gamma, beta, a, b);
+    const uint32_t P = (uint32_t)g.B * g.Ho * g.Wo;
+    const uint32_t p = blockIdx.x * m.R + m.rl;  // pooled pixel: one chunk of R pixels per block, in address order
+    if (p >= P) return;
+    uint32_t t = fdiv(p, g.dw);
+    const int wo = (int)(p - t * g.dw.d);
+    const uint32_t bb = fdiv(t, g.dh);
+    const int ho = (int)(t - bb * g.dh.d);
+    float best[8];
+    uint8_t arg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        best[k] = -INFINITY;
+        arg[k] = 0;
+    }
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int hi = ho * 2 - 1 + r;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int wi = wo * 2 - 1 + s;
+            if (hi < 0 || hi >= g.H || wi < 0 || wi >= g.W) continue;
+            const bf16x8 v = ld8(u + (uint32_t)((((int)bb * g.H + hi) * g.W + wi) * g.C + m.cg * 8));
+            const uint8_t tap = (uint8_t)(r * 3 + s);
+            unsigned bits = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float pre = (float)v[k] * a[k] + b[k];
+                bits |= (pre > 0.f ? 1u : 0u) << k;
+                // the value the unfused path would have stored: bf16(relu(a*u + b))
+                const float f = (float)(bf16)fmaxf(pre, 0.f);
+                if (!any) arg[k] = tap;
+                if (f > best[k] || f != f) {
+                    best[k] = f;
+                    arg[k] = tap;
+                }
+            }
+            any = true;
+            if (r >= 1 && s >= 1)  // this window owns pixel (2ho + r - 1, 2wo + s - 1)
+                mask[(uint32_t)((((int)bb * g.H + hi) * g.W + wi)) * (uint32_t)m.G + m.cg] = (uint8_t)bits;
+        }
+    }
+    const uint32_t off = p * (uint32_t)g.C + m.cg * 8;
+    bf16x8 o;
+    uint64_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        o[k] = (bf16)best[k];
+        packed |= (uint64_t)arg[k] << (8 * k);
+    }
+    *reinterpret_cast<bf16x8*>(y + off) = o;
+    *reinterpret_cast<uint64_t*>(argmax + off) = packed;
+}
+
 int grid_for(long M, int C) {
     const int R = kThreads / (C >> 3);
     long parts = (M + (long)R * 16 - 1) / ((long)R * 16);
@@ -483,6 +573,33 @@ void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx,
     else if (dres) PDT_ELEMT(false, true);
     else PDT_ELEMT(false, false);
 #undef PDT_ELEMT
+}
+
+namespace {
+PoolGeom pool_geom(int B, int H, int W, int C, int Ho, int Wo, bool backward) {
+    PoolGeom g;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo;
+    g.dw = make_fastdiv((uint32_t)(backward ? W : Wo));
+    g.dh = make_fastdiv((uint32_t)(backward ? H : Ho));
+    return g;
+}
+void check_pool_index_space(long pixels, int C) {
+    if (pixels * C >= (1L << 31)) {
+        fprintf(stderr, "bn_relu_maxpool: %ld elements do not fit the 31-bit index space of the kernels\n", pixels * C);
+        abort();
+    }
+}
+}  // namespace
+
+void launch_bn_relu_maxpool_fwd(const void* u, void* y, uint8_t* argmax, uint8_t* mask, int B, int H, int W, int C,
+                                int Ho, int Wo,
+                                const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                hipStream_t s) {
+    check_pool_index_space((long)B * H * W, C);
+    const int R = kThreads / (C >> 3);
+    const long P = (long)B * Ho * Wo;
+    hipLaunchKernelGGL(k_bn_relu_maxpool_fwd, dim3((unsigned)((P + R - 1) / R)), dim3(kThreads), 0, s, (const bf16*)u,
+                       (bf16*)y, argmax, mask, pool_geom(B, H, W, C, Ho, Wo, false), mean, invstd, gamma, beta);
 }
 
 }  // namespace pdt

@@ -78,6 +78,11 @@ struct BnAffine {
 void launch_bn_apply(const void* x, const void* residual, void* z, uint8_t* mask /*[M][C/8] or null*/, long M, int C,
                      const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
                      const BnAffine& res_affine, hipStream_t s);
+// stem tail fused: y = maxpool3x3/2/1(relu(bn(u))) without the full-resolution activation in memory; also writes
+// the winning taps and the 1-bit ReLU mask [B*H*W][C/8] of the full-resolution pixels
+void launch_bn_relu_maxpool_fwd(const void* u, void* y, uint8_t* argmax, uint8_t* mask, int B, int H, int W, int C,
+                                int Ho, int Wo, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, hipStream_t s);
 void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, int C, const float* mean,
                           const float* invstd, int relu, float* slab /*[parts][2][C]*/, int parts,
                           hipStream_t s);

@@ -22,7 +22,7 @@ import torch
 import torch.nn as tnn
 
 from .. import nn as pnn
-from ..nn.functional import conv_bn_act
+from ..nn.functional import conv_bn_act, conv_bn_relu_maxpool
 
 _LAZY_RES = os.environ.get("PDT_LAZY_RES_GRAD", "1") != "0"  # A/B knob for the gated residual gradient
 _DEFER_DS = os.environ.get("PDT_DEFER_DS_BN", "1") != "0"    # A/B knob: downsample BN applied by its consumer
@@ -128,8 +128,7 @@ class ResNet(tnn.Module):
         return tnn.Sequential(*layers)
 
     def forward(self, x):
-        x = conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        x = self.maxpool(x)
+        x = conv_bn_relu_maxpool(x, self.conv1, self.bn1, self.maxpool)  # BN + ReLU + pool: one fused node
         x = self.layer1(x)
         x = self.layer2(x)
         x = self.layer3(x)

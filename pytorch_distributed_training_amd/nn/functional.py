@@ -23,6 +23,7 @@ import os
 
 import torch
 import torch.distributed as tdist
+import torch.nn as tnn
 
 from ..ops import backend_for, reference
 
@@ -194,6 +195,38 @@ class _BNSink:
         return ps if ok else None
 
 
+def _bn_moments(be, x, stats, cfg: BNConfig):
+    """Batch (or running) mean / invstd of ``x`` for one BN node -> ``(mean, invstd, count, count_t, world)``.
+    In training with SyncBN the packed ``[sum, sum_sq, count]`` is all-reduced once (no host sync)."""
+    world = _sync_world(cfg)
+    b, c, h, w = x.shape
+    count = float(b * h * w)
+    count_t = None
+    if cfg.training:
+        if stats is None:
+            stats = be.bn_stats(x)
+        if world > 1:
+            # [sum(C), sum_sq(C), count]: one all-reduce, counts may differ per rank
+            packed = torch.empty(2 * c + 4, dtype=torch.float32, device=x.device)
+            packed[: 2 * c].copy_(be.bn_sum_partials(stats).reshape(-1))
+            packed[2 * c:] = count
+            tdist.all_reduce(packed, group=cfg.group)
+            stats = packed[: 2 * c].view(1, 2, c)
+            count_t = packed[2 * c: 2 * c + 1]
+        cnt = count_t if count_t is not None else count
+        mom = 0.0
+        if cfg.running_mean is not None:
+            mom = cfg.momentum
+            if mom is None:  # cumulative moving average (host sync, like the stock module)
+                mom = 1.0 / (float(cfg.num_batches_tracked.item()) + 1.0)
+        mean, invstd = be.bn_finalize(stats, cnt, cfg.eps, cfg.running_mean, cfg.running_var, mom,
+                                      cfg.num_batches_tracked if cfg.running_mean is not None else None)
+    else:
+        mean = cfg.running_mean.float()
+        invstd = torch.rsqrt(cfg.running_var.float() + cfg.eps)
+    return mean, invstd, count, count_t, world
+
+
 class _PendingAffine:
     """A ReLU-less BN whose ONLY consumer is the residual input of another BN node (the downsample branch) does not
     have to write its output: it returns its input untouched together with this holder, and the consumer applies
@@ -221,32 +254,8 @@ class _BNActFn(torch.autograd.Function):
             if why is not None:
                 _note_fallback("bn_act", why)
                 be = reference
-        world = _sync_world(cfg)
-        b, c, h, w = x.shape
-        count = float(b * h * w)
-        count_t = None
-        if cfg.training:
-            if stats is None:
-                stats = be.bn_stats(x)
-            if world > 1:
-                # [sum(C), sum_sq(C), count]: one all-reduce, counts may differ per rank
-                packed = torch.empty(2 * c + 4, dtype=torch.float32, device=x.device)
-                packed[: 2 * c].copy_(be.bn_sum_partials(stats).reshape(-1))
-                packed[2 * c:] = count
-                tdist.all_reduce(packed, group=cfg.group)
-                stats = packed[: 2 * c].view(1, 2, c)
-                count_t = packed[2 * c: 2 * c + 1]
-            cnt = count_t if count_t is not None else count
-            mom = 0.0
-            if cfg.running_mean is not None:
-                mom = cfg.momentum
-                if mom is None:  # cumulative moving average (host sync, like the stock module)
-                    mom = 1.0 / (float(cfg.num_batches_tracked.item()) + 1.0)
-            mean, invstd = be.bn_finalize(stats, cnt, cfg.eps, cfg.running_mean, cfg.running_var, mom,
-                                          cfg.num_batches_tracked if cfg.running_mean is not None else None)
-        else:
-            mean = cfg.running_mean.float()
-            invstd = torch.rsqrt(cfg.running_var.float() + cfg.eps)
+        mean, invstd, count, count_t, world = _bn_moments(be, x, stats, cfg)
+        c = x.shape[1]
         g32 = gamma.float() if gamma is not None else torch.ones(c, device=x.device)
         b32 = beta.float() if beta is not None else torch.zeros(c, device=x.device)
         ctx.defer = defer
@@ -448,6 +457,57 @@ class _GlobalAvgPoolFn(torch.autograd.Function):
         return ctx.be.global_avgpool_bwd(dy.contiguous(), ctx.shape)
 
 
+class _BNReluPoolFn(torch.autograd.Function):
+    """``maxpool3x3/2/1(relu(bn(u)))`` as ONE node (the ResNet stem tail: /root/reference/main.py:40 builds
+    torchvision's conv1 -> bn1 -> relu -> maxpool).  The forward reads the conv output once and writes the pooled
+    tensor, the winning taps and the 1-bit ReLU mask; the full-resolution activation is never written.  Backward:
+    pool backward, then the BN backward kernels gated by the mask."""
+
+    @staticmethod
+    def forward(ctx, u, gamma, beta, stats, cfg: BNConfig):
+        be = backend_for(u)
+        u = _cl(u)
+        if be is not reference:
+            why = be.bn_unsupported_reason(u)
+            if why is not None:
+                _note_fallback("bn_relu_maxpool", why)
+                be = reference
+        mean, invstd, count, count_t, world = _bn_moments(be, u, stats, cfg)
+        c = u.shape[1]
+        g32 = gamma.float() if gamma is not None else torch.ones(c, device=u.device)
+        b32 = beta.float() if beta is not None else torch.zeros(c, device=u.device)
+        y, aux, act = be.bn_relu_maxpool_fwd(u, mean, invstd, g32, b32)
+        ctx.save_for_backward(u, y, aux, act, mean, invstd, g32, count_t)
+        ctx.cfg = (be, cfg, world, count, None if gamma is None else gamma.dtype, None if beta is None else beta.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, y, aux, act, mean, invstd, g32, count_t = ctx.saved_tensors
+        be, cfg, world, count, gdt, bdt = ctx.cfg
+        # (the oracle's pool backward recomputes the pooling from its input: hand it the activation it kept)
+        dz = be.maxpool3x3s2_bwd(_cl(dy), act if be is reference else u, y, aux)
+        psums = be.bn_bwd_reduce(dz, act, u, mean, invstd, True)
+        if cfg.training and world > 1:
+            sums = be.bn_sum_partials(psums)
+            gsums = sums.clone()
+            tdist.all_reduce(gsums, group=cfg.group)
+            du, _, _ = be.bn_bwd_elemt(dz, act, u, mean, invstd, g32, gsums.view(1, 2, -1), count_t, True, False)
+        elif cfg.training:
+            du, _, sums = be.bn_bwd_elemt(dz, act, u, mean, invstd, g32, psums, count, True, False)
+        else:
+            sums = be.bn_sum_partials(psums)
+            du, _, _ = be.bn_bwd_elemt(dz, act, u, mean, invstd, g32, torch.zeros_like(sums).view(1, 2, -1), 1.0,
+                                       True, False)
+        dgamma = sums[1].to(gdt) if (gdt is not None and ctx.needs_input_grad[1]) else None
+        dbeta = sums[0].to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
+        return (du if ctx.needs_input_grad[0] else None), dgamma, dbeta, None, None
+
+
+def bn_relu_maxpool(u, gamma, beta, cfg: BNConfig, stats=None):
+    return _BNReluPoolFn.apply(u, gamma, beta, stats, cfg)
+
+
 def global_avgpool(x):
     """``[B,C,H,W] -> [B,C]`` (adaptive avg-pool to 1x1 + flatten)."""
     return _GlobalAvgPoolFn.apply(x)
@@ -518,3 +578,31 @@ def conv_bn_act(x, conv, bn, relu: bool = True, residual=None, return_skip: bool
         y, stats = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats)
     return done(bn(y, residual=residual, relu=relu, stats=stats, lazy_residual_grad=lazy_residual_grad,
                    defer_apply=defer_apply), skip)
+
+
+def conv_bn_relu_maxpool(x, conv, bn, pool):
+    """``pool(relu(bn(conv(x))))`` for the ResNet stem; the BN + ReLU + 3x3/2/1 max-pool tail runs as one fused
+    node when the modules are the plain ones, else the unfused composition."""
+    from .modules import BatchNorm2d, Conv2d  # local: avoid cycle
+
+    from .modules import MaxPool3x3s2
+
+    std_pool = isinstance(pool, MaxPool3x3s2) or (
+        isinstance(pool, tnn.MaxPool2d) and pool.kernel_size in (3, (3, 3)) and pool.stride in (2, (2, 2))
+        and pool.padding in (1, (1, 1)) and pool.dilation in (1, (1, 1)) and not pool.ceil_mode
+        and not pool.return_indices)
+    fusable = (
+        std_pool and _FUSE_STEM_POOL and not _PLAIN_TORCH and isinstance(conv, Conv2d) and isinstance(bn, BatchNorm2d)
+        and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1) and conv.stride[0] == conv.stride[1]
+        and conv.padding[0] == conv.padding[1] and conv.kernel_size[0] == conv.kernel_size[1]
+    )
+    if not fusable:
+        y = conv_bn_act(x, conv, bn, relu=True)
+        return maxpool3x3s2(y) if std_pool else pool(y)
+    want_stats = bn.training or not bn.track_running_stats
+    y, stats = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats)
+    cfg = bn._cfg()
+    return bn_relu_maxpool(y, bn.weight, bn.bias, cfg, stats if cfg.training else None)
+
+
+_FUSE_STEM_POOL = os.environ.get("PDT_FUSE_STEM_POOL", "1") != "0"  # A/B knob

@@ -237,6 +237,12 @@ def maxpool3x3s2_bwd(dy, x, y, argmax):
     return _C.maxpool3x3s2_bwd(dy, argmax, list(x.shape))
 
 
+def bn_relu_maxpool_fwd(u, mean, invstd, gamma, beta):
+    """``maxpool3x3/2/1(relu(bn(u)))`` in one pass over the conv output -> (y, argmax taps uint8 [B,Ho,Wo,C],
+    1-bit ReLU mask [B*H*W, C/8] of the full-resolution activation, which is never written)"""
+    return _C.bn_relu_maxpool_fwd(u, mean, invstd, gamma.contiguous(), beta.contiguous())
+
+
 def global_avgpool_fwd(x):
     return _C.global_avgpool_fwd(x)
 

@@ -201,6 +201,13 @@ def maxpool3x3s2_bwd(dy, x, y, aux=None):
     return g.to(x.dtype)
 
 
+def bn_relu_maxpool_fwd(u, mean, invstd, gamma, beta):
+    """Oracle of the fused stem tail: the same composition of ops the unfused path runs -> (y, aux, act) with
+    ``act`` what the BN backward ops gate the ReLU with (here the full-resolution activation itself)."""
+    z, act = bn_apply_act(u, mean, invstd, gamma, beta, None, True)
+    return F.max_pool2d(z, 3, 2, 1), None, act
+
+
 def global_avgpool_fwd(x):
     return x.float().mean((2, 3)).to(x.dtype)
 
