@@ -265,16 +265,33 @@ inline int tile_w(int dim) { return dim % 128 == 0 ? 128 : 64; }
 
 }  // namespace
 
-static const long kTargetBlocks = [] {
+// Workgroups the split-K factor aims for.  Pointwise layers want ~4 per CU (1024).  Spatial filters want shorter
+// splits: the taps of a split are adjacent workgroups that stream the same dY / X rows, and they only hit each
+// other's lines in L2 while they stay close together; B=1024 sweep (bench/resnet50_roofline.py): 2048 gives
+// -4..-12 % on the 128..512-channel 3x3s, and the 64-channel 3x3 (nine 64x64 tiles, fetch-bound) wants the
+// 512-split cap (610 -> 495 us).  PDT_WGRAD_BLOCKS overrides all of them.
+static const long kTargetBlocksEnv = [] {
     const char* e = std::getenv("PDT_WGRAD_BLOCKS");
-    return e ? std::atol(e) : 1024L;
+    return e ? std::atol(e) : 0L;
 }();
+static long target_blocks(const WgradGeom& g) {
+    if (kTargetBlocksEnv > 0) return kTargetBlocksEnv;
+    if (g.KH * g.KW == 1) return 1024;
+    return (g.C <= 64 && g.N <= 64) ? 8192 : 2048;
+}
 
 int conv_wgrad_splits(const WgradGeom& g) {
     const int tn = tile_w(g.N), tc = tile_w(g.C);
     const long tiles = (long)((g.N + tn - 1) / tn) * ((g.C + tc - 1) / tc) * g.KH * g.KW;
     const long M = (long)g.B * g.Hout * g.Wout;
-    long splits = (kTargetBlocks + tiles - 1) / tiles;
+    long splits = (target_blocks(g) + tiles - 1) / tiles;
+    if (kTargetBlocksEnv <= 0 && g.KH * g.KW > 1) {
+        // the larger spatial-filter targets were measured with >= 4096 pixels per split; smaller batches keep at
+        // least the pointwise target
+        const long base = (1024 + tiles - 1) / tiles;
+        const long by_len = M / 4096;
+        if (splits > by_len) splits = by_len > base ? by_len : base;
+    }
     const long max_splits = (M + 4 * KM - 1) / (4 * KM);  // at least 4 K-steps per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
