@@ -177,6 +177,17 @@ def check_conv(args, time_it):
         ref_gate = (gate_src > 0)
         e2 = max(e2, rel_err(native.apply_relu_gate(add, gmask), add * ref_gate))
         record(f"conv_dgrad+gated_addend {tag}", e2 < 2e-3, e2, {})
+        # compact stride-2 addend (gradient of a 1x1 stride-2 conv of the same input) == its zero-stuffed form
+        if H % 2 == 0 and W % 2 == 0:
+            comp = nhwc(B, C, H // 2, W // 2)
+            full = torch.zeros_like(add)
+            full[:, :, ::2, ::2] = comp
+            dx7, ps7 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, comp, (xb, act, mean, invstd), None, 2)
+            dx8, ps8 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, full, (xb, act, mean, invstd))
+            dx9 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, comp, addend_stride=2)
+            e3 = max(rel_err(dx7, dx8), rel_err(dx9, dx8),
+                     rel_err(native.bn_sum_partials(ps7), native.bn_sum_partials(ps8)))
+            record(f"conv_dgrad+compact_addend {tag}", e3 < 1e-6, e3, {})
 
     run_case(f"conv_fwd   {tag}", fwd)
     run_case(f"conv_dgrad {tag}", dgrad)

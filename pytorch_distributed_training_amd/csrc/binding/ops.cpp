@@ -131,14 +131,22 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
                                         int64_t KW, int64_t stride, int64_t pad, const c10::optional<Tensor>& addend,
                                         const c10::optional<Tensor>& bn_x, const c10::optional<Tensor>& bn_mask,
                                         const c10::optional<Tensor>& bn_mean, const c10::optional<Tensor>& bn_invstd,
-                                        const c10::optional<Tensor>& addend_mask) {
+                                        const c10::optional<Tensor>& addend_mask, int64_t addend_stride) {
     check_nhwc_bf16(dy, "dy");
+    TORCH_CHECK(addend_stride == 1 || addend_stride == 2, "addend_stride must be 1 or 2");
     const bool bnr = bn_x.has_value() && bn_x->defined();
     const void* addend_ptr = nullptr;
     const uint8_t* addend_mask_ptr = nullptr;
     if (addend.has_value() && addend->defined()) {
         check_nhwc_bf16(*addend, "addend");
-        TORCH_CHECK(addend->sizes().vec() == x_shape, "addend must have the shape of dx");
+        if (addend_stride == 2) {
+            TORCH_CHECK(addend->size(0) == x_shape[0] && addend->size(1) == x_shape[1] &&
+                            addend->size(2) == (x_shape[2] + 1) / 2 && addend->size(3) == (x_shape[3] + 1) / 2,
+                        "compact stride-2 addend must be [B, C, ceil(H/2), ceil(W/2)]");
+            TORCH_CHECK(!(addend_mask.has_value() && addend_mask->defined()), "compact addend takes no mask");
+        } else {
+            TORCH_CHECK(addend->sizes().vec() == x_shape, "addend must have the shape of dx");
+        }
         TORCH_CHECK(stride == 1, "addend fusion is implemented for stride-1 data gradients");
         addend_ptr = addend->data_ptr();
         if (addend_mask.has_value() && addend_mask->defined()) {
@@ -184,6 +192,7 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
             }
         g.addend = addend_ptr;
         g.addend_mask = addend_mask_ptr;
+        g.addend_stride = (int)addend_stride;
         Tensor psums, slab;
         float* slab_ptr = nullptr;
         int m_tiles = 0;
@@ -901,7 +910,7 @@ void bind_ops(pybind11::module& m) {
           pybind11::arg("kw"), pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("addend") = pybind11::none(),
           pybind11::arg("bn_x") = pybind11::none(), pybind11::arg("bn_mask") = pybind11::none(),
           pybind11::arg("bn_mean") = pybind11::none(), pybind11::arg("bn_invstd") = pybind11::none(),
-          pybind11::arg("addend_mask") = pybind11::none());
+          pybind11::arg("addend_mask") = pybind11::none(), pybind11::arg("addend_stride") = 1);
     m.def("conv2d_wgrad", &conv2d_wgrad);
     m.def("conv_stem_fwd", &conv_stem_fwd);
     m.def("stem_pack_x", &stem_pack_x);

@@ -384,7 +384,19 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                 pix = (b * g.Hout + (i * g.os + g.ooh)) * g.Wout + (j * g.os + g.oow);
             }
             bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * OPITCH + och * 16);
-            if (g.addend != nullptr) {
+            if (g.addend != nullptr && g.addend_stride == 2) {
+                // compact stride-2 addend (dense stride-1 launch: pix == m): only even (h, w) receive a term
+                const int w_ = (int)(m % g.Wout);
+                const long t_ = m / g.Wout;
+                const int h_ = (int)(t_ % g.Hout);
+                if (((w_ | h_) & 1) == 0) {
+                    const long b_ = t_ / g.Hout;
+                    const long cp = (b_ * ((g.Hout + 1) >> 1) + (h_ >> 1)) * ((g.Wout + 1) >> 1) + (w_ >> 1);
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.addend) + cp * g.N + ncol);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)a[k]);
+                }
+            } else if (g.addend != nullptr) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.addend) + pix * g.N + ncol);
                 const unsigned abits = g.addend_mask != nullptr ? g.addend_mask[(pix * g.N + ncol) >> 3] : 0xffu;
 #pragma unroll

@@ -139,6 +139,10 @@ struct ConvGeom {
     // epilogue adds addend where the bit is set.  Lets the residual branch hand over the UNMASKED gradient that
     // reached the block output plus that ReLU's mask instead of materialising the masked copy.
     const uint8_t* addend_mask;
+    // addend_stride == 2: the addend is the COMPACT data gradient of a 1x1 stride-2 convolution of the same input
+    // (the downsample branch): shape [B, ceil(Hout/2), ceil(Wout/2), N], added at the even (h, w) positions only.
+    // Saves zero-filling a full-size tensor and reading it back (3/4 of it zeros).
+    int addend_stride;
     // elements per input pixel in memory; 0 = C (dense NHWC).  The packed stem runs with C = 32 (one filter
     // row: 8 kw slots x 4 channels, contiguous in memory) over pixels of 4 elements.
     int pix_elems;

@@ -26,6 +26,7 @@ from ..nn.functional import conv_bn_act, conv_bn_relu_maxpool
 
 _LAZY_RES = os.environ.get("PDT_LAZY_RES_GRAD", "1") != "0"  # A/B knob for the gated residual gradient
 _DEFER_DS = os.environ.get("PDT_DEFER_DS_BN", "1") != "0"    # A/B knob: downsample BN applied by its consumer
+_COMPACT_DS = os.environ.get("PDT_COMPACT_DS_GRAD", "1") != "0"  # A/B knob: stride-2 downsample dgrad kept compact
 
 
 def _conv3x3(cin, cout, stride=1):
@@ -55,7 +56,8 @@ class BasicBlock(tnn.Module):
         out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, return_skip=True)
         if self.downsample is not None:
             # the downsample BN's affine is applied by the block-output node while it reads the residual
-            identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False, defer_apply=_DEFER_DS)
+            identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False, defer_apply=_DEFER_DS,
+                                   compact_skip_grad=_COMPACT_DS)
         # identity has exactly one consumer (this node): its gradient may come back ungated + mask
         return conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=identity, lazy_residual_grad=_LAZY_RES)
 
@@ -81,7 +83,8 @@ class Bottleneck(tnn.Module):
         out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, return_skip=True)
         if self.downsample is not None:
             # the downsample BN's affine is applied by the block-output node while it reads the residual
-            identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False, defer_apply=_DEFER_DS)
+            identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False, defer_apply=_DEFER_DS,
+                                   compact_skip_grad=_COMPACT_DS)
         out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
         return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=identity, lazy_residual_grad=_LAZY_RES)
 

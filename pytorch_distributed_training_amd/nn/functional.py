@@ -80,7 +80,7 @@ class _Conv2dFn(torch.autograd.Function):
     kernel's epilogue, instead of autograd summing two activation-sized tensors with a separate add."""
 
     @staticmethod
-    def forward(ctx, x, w, w_lp, stride, padding, want_stats, with_skip):
+    def forward(ctx, x, w, w_lp, stride, padding, want_stats, with_skip, compact_to=None):
         wk = w_lp if w_lp is not None else w
         be = backend_for(x)
         if be is not reference:
@@ -95,6 +95,10 @@ class _Conv2dFn(torch.autograd.Function):
         if sink is not None and not (be is not reference and stride == 1 and sink.usable_for(x)):
             sink = None
         ctx.bn_sink = sink
+        # 1x1 stride-2 conv on the skip of another conv node (downsample branch): its data gradient only touches
+        # the even pixels, so it is handed to that node COMPACT (side channel, see backward) instead of as a
+        # zero-filled full-size tensor that the other node would read back
+        ctx.compact_to = compact_to
         y, stats, saved = be.conv2d_fwd(x, wk, stride, padding, want_stats, True)
         ctx.set_materialize_grads(False)  # no zero-filled gradient for the (non-differentiable) stats output
         ctx.save_for_backward(saved, wk)  # `saved` is x, or the packed image of the native 3-channel stem
@@ -108,14 +112,26 @@ class _Conv2dFn(torch.autograd.Function):
         x, wk = ctx.saved_tensors
         be, stride, padding, w_shape, w_dtype, x_shape = ctx.cfg
         dx = dw = None
+        compact = ctx.__dict__.pop("strided_addend", None)  # left here by the downsample conv's backward
+        if compact is not None and dskip is not None:
+            raise RuntimeError("compact skip gradient: the skip tensor also received a dense gradient")
         gate = _take_gate(dskip, getattr(ctx, "expect_gate", False))
         if dy is None:
-            return (dskip if gate is None else be.apply_relu_gate(_cl(dskip), gate)), None, None, None, None, None, None
+            return (dskip if gate is None else be.apply_relu_gate(_cl(dskip), gate)), None, None, None, None, None, None, None
         dy = _cl(dy)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.compact_to is not None:
+            b, _, ho, wo = dy.shape
+            ctx.compact_to.strided_addend = be.conv2d_dgrad(dy, wk, (b, x_shape[1], ho, wo), 1, 0)
+        elif ctx.needs_input_grad[0]:
             sink = ctx.bn_sink
             dskip = None if dskip is None else _cl(dskip)
-            if sink is not None:
+            if compact is not None:
+                if sink is not None:
+                    dx, psums = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, compact, sink.operands(), None, 2)
+                    sink.fulfil(dx, psums)
+                else:
+                    dx = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, compact, addend_stride=2)
+            elif sink is not None:
                 dx, psums = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, dskip, sink.operands(), gate)
                 sink.fulfil(dx, psums)
             elif gate is not None:
@@ -126,16 +142,23 @@ class _Conv2dFn(torch.autograd.Function):
             dw = be.conv2d_wgrad(dy, x, w_shape, stride, padding)
             if dw.dtype != w_dtype:
                 dw = dw.to(w_dtype)
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
-def conv2d(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = False, with_skip: bool = False):
+def conv2d(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = False, with_skip: bool = False,
+           compact_skip_grad: bool = False):
     """Bias-free square-stride conv.  Returns ``(y, stats)`` (+ ``skip`` when ``with_skip``) where ``stats``
     is the fp32 partial rows ``[P, 2, Cout]`` of the per-channel ``[sum, sum_sq]`` of ``y`` (or ``None``)."""
     w_lp = getattr(weight, "_lp", None)
     if w_lp is not None and w_lp.dtype != x.dtype:
         w_lp = None
-    y, stats, skip = _Conv2dFn.apply(x, weight, w_lp, int(stride), int(padding), bool(want_stats), bool(with_skip))
+    compact_to = None
+    if (compact_skip_grad and int(stride) == 2 and int(padding) == 0 and tuple(weight.shape[2:]) == (1, 1)
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and torch.is_grad_enabled() and x.requires_grad
+            and getattr(x, "_pdt_lazy_grad_ok", False) and type(x.grad_fn).__name__ == "_Conv2dFnBackward"):
+        compact_to = x.grad_fn  # caller's promise: x (a stride-1 conv node's skip output) has no other consumer
+    y, stats, skip = _Conv2dFn.apply(x, weight, w_lp, int(stride), int(padding), bool(want_stats), bool(with_skip),
+                                     compact_to)
     if with_skip and skip is not None:
         skip._pdt_lazy_grad_ok = int(stride) == 1  # the masked-addend epilogue exists for stride-1 data gradients
     return (y, stats, skip) if with_skip else (y, stats)
@@ -535,7 +558,7 @@ def softmax_cross_entropy(logits, labels):
 
 # ------------------------------------------------------------------ helpers
 def conv_bn_act(x, conv, bn, relu: bool = True, residual=None, return_skip: bool = False,
-                lazy_residual_grad: bool = False, defer_apply: bool = False):
+                lazy_residual_grad: bool = False, defer_apply: bool = False, compact_skip_grad: bool = False):
     """``act(bn(conv(x)) [+ residual])`` through the fused nodes.
 
     ``conv``/``bn`` are modules (parameter containers); bias-free square convs with dilation 1 and
@@ -575,7 +598,8 @@ def conv_bn_act(x, conv, bn, relu: bool = True, residual=None, return_skip: bool
     if return_skip and torch.is_grad_enabled() and x.requires_grad:
         y, stats, skip = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats, with_skip=True)
     else:
-        y, stats = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats)
+        y, stats = conv2d(x, conv.weight, conv.stride[0], conv.padding[0], want_stats=want_stats,
+                          compact_skip_grad=compact_skip_grad)
     return done(bn(y, residual=residual, relu=relu, stats=stats, lazy_residual_grad=lazy_residual_grad,
                    defer_apply=defer_apply), skip)
 

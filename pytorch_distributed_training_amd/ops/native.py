@@ -109,20 +109,24 @@ def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False, return
     return (y, stats, saved) if return_saved else (y, stats)
 
 
-def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None, bn_sink=None, addend_mask=None):
+def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None, bn_sink=None, addend_mask=None,
+                 addend_stride: int = 1):
     """``bn_sink = (x, mask, mean, invstd)`` of the BN+ReLU that produced this conv's input: the kernel epilogue
     then also reduces that BN's backward sums and the call returns ``(dx, psums)`` (stride 1 only).
     ``addend_mask``: 1-bit activity mask ``[pixels, C/8]`` gating the addend (stride 1 only)."""
     kh, kw = w.shape[2], w.shape[3]
     wt = _transposed(w)  # [Cin][taps][Cout]: K-contiguous operand for the dgrad GEMM
+    if addend_stride != 1:
+        assert stride == 1 and addend_mask is None, "compact stride-2 addend: stride-1 data gradients only"
     if addend_mask is not None and stride != 1:
         addend, addend_mask = apply_relu_gate(addend, addend_mask), None
     if bn_sink is not None:
-        return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend, *bn_sink, addend_mask)
+        return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend, *bn_sink, addend_mask,
+                               addend_stride)
     if addend is not None and stride != 1:
         return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, None)[0] + addend
     return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend, None, None, None, None,
-                           addend_mask)[0]
+                           addend_mask, addend_stride)[0]
 
 
 def apply_relu_gate(g, mask):

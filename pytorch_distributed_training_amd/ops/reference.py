@@ -23,11 +23,15 @@ def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False, return
     return (y, stats, x) if return_saved else (y, stats)
 
 
-def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None, addend_mask=None):
+def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None, addend_mask=None, addend_stride: int = 1):
     """``addend_mask``: activity "mask" of a BN+ReLU as this backend keeps it (the post-ReLU output itself);
     the addend only counts where that ReLU was active."""
     dx = _conv2d_dgrad(dy, w, x_shape, stride, padding)
     if addend is None:
+        return dx
+    if addend_stride == 2:  # compact gradient of a 1x1 stride-2 conv of the same input: lands on the even pixels
+        dx = dx.clone()
+        dx[:, :, ::2, ::2] += addend.to(dx.dtype)
         return dx
     if addend_mask is not None:
         addend = addend * (addend_mask > 0).to(addend.dtype)

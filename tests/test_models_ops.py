@@ -434,3 +434,38 @@ def test_deferred_bn_refuses_unaware_consumer():
     y = conv_bn_act(x, c, b, relu=False, defer_apply=True)
     with pytest.raises(RuntimeError, match="deferred BatchNorm apply"):
         y.sum().backward()
+
+
+def test_compact_downsample_grad_matches_dense(monkeypatch):
+    """The 1x1 stride-2 downsample conv hands its data gradient to the block's first conv compact
+    ([B, C, H/2, W/2], side channel on the producer's ctx) instead of zero-filled at full size."""
+    import pytorch_distributed_training_amd.models.resnet as R
+    import pytorch_distributed_training_amd.ops.reference as ref
+    from pytorch_distributed_training_amd.models import build_model
+
+    def run(flag):
+        monkeypatch.setattr(R, "_COMPACT_DS", flag)
+        used = []
+        orig = ref.conv2d_dgrad
+
+        def spy(*a, **k):
+            if (len(a) > 8 and a[8] == 2) or k.get("addend_stride", 1) == 2:
+                used.append(1)
+            return orig(*a, **k)
+        monkeypatch.setattr(ref, "conv2d_dgrad", spy)
+        torch.manual_seed(0)
+        m = build_model("resnet50", 10)
+        x = torch.randn(2, 3, 32, 32, requires_grad=True)
+        m(x).square().sum().backward()
+        return len(used), x.grad.clone(), [p.grad.clone() for p in m.parameters()]
+
+    n1, gx1, gp1 = run(True)
+    n0, gx0, gp0 = run(False)
+    assert n1 == 3 and n0 == 0  # layer2/3/4 open with a stride-2 downsample
+
+    def close(a, b):  # same sums in a different order: compare against the tensor's scale
+        return float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-12
+
+    assert close(gx1, gx0)
+    for a, b in zip(gp1, gp0):
+        assert close(a, b)
