@@ -445,20 +445,41 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_maxpool_fwd(const bf16* __
     float a[8], b[8];
     bn_coeffs(m, mean, invstd, gamma, beta, a, b);
     const uint32_t P = (uint32_t)g.B * g.Ho * g.Wo;
-    const uint32_t p = blockIdx.x * m.R + m.rl;  // pooled pixel: one chunk of R pixels per block, in address order
+    // pooled pixel: one chunk of R pixels per block; runs of 64 consecutive chunks (about 37 image rows) go to one
+    // XCD so that the input rows two neighbouring output rows share are fetched into ONE L2
+    uint32_t blk = blockIdx.x;
+    {
+        constexpr uint32_t GRP = 64;
+        const uint32_t full = gridDim.x / (8 * GRP) * (8 * GRP);
+        if (blk < full) {
+            const uint32_t xcd = blk & 7, slot = blk >> 3;
+            blk = ((slot / GRP) * 8 + xcd) * GRP + slot % GRP;
+        }
+    }
+    const uint32_t p = blk * m.R + m.rl;
     if (p >= P) return;
     uint32_t t = fdiv(p, g.dw);
     const int wo = (int)(p - t * g.dw.d);
     const uint32_t bb = fdiv(t, g.dh);
     const int ho = (int)(t - bb * g.dh.d);
-    float best[8];
-    uint8_t arg[8];
+    // all nine taps are loaded up front from CLAMPED coordinates (the out-of-image ones are ignored below)
+    bf16x8 v9[9];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        best[k] = -INFINITY;
-        arg[k] = 0;
+    for (int r = 0; r < 3; ++r) {
+        const int hi = min(max(ho * 2 - 1 + r, 0), g.H - 1);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int wi = min(max(wo * 2 - 1 + s, 0), g.W - 1);
+            v9[r * 3 + s] = ld8(u + (uint32_t)((((int)bb * g.H + hi) * g.W + wi) * g.C + m.cg * 8));
+        }
     }
-    bool any = false;
+    // The kernel is VALU-bound (a first version: 1500 vector instructions per thread = the whole run time), so value
+    // and winning tap travel in ONE integer key per channel: post-ReLU values are >= +0, so their bf16 bit patterns
+    // order like the numbers; key = bf16 << 16 | (8 - tap), and one v_max_u32 per tap keeps the largest value and,
+    // among equals, the FIRST tap in scan order (what ATen's pool records).
+    uint32_t key[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) key[k] = 0u;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int hi = ho * 2 - 1 + r;
@@ -466,36 +487,34 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_maxpool_fwd(const bf16* __
         for (int s = 0; s < 3; ++s) {
             const int wi = wo * 2 - 1 + s;
             if (hi < 0 || hi >= g.H || wi < 0 || wi >= g.W) continue;
-            const bf16x8 v = ld8(u + (uint32_t)((((int)bb * g.H + hi) * g.W + wi) * g.C + m.cg * 8));
-            const uint8_t tap = (uint8_t)(r * 3 + s);
+            const bf16x8 v = v9[r * 3 + s];
+            const uint32_t code = (uint32_t)(8 - (r * 3 + s));
             unsigned bits = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float pre = (float)v[k] * a[k] + b[k];
-                bits |= (pre > 0.f ? 1u : 0u) << k;
-                // the value the unfused path would have stored: bf16(relu(a*u + b))
-                const float f = (float)(bf16)fmaxf(pre, 0.f);
-                if (!any) arg[k] = tap;
-                if (f > best[k] || f != f) {
-                    best[k] = f;
-                    arg[k] = tap;
-                }
+            for (int k = 0; k < 8; k += 2) {
+                const float p0 = (float)v[k] * a[k] + b[k], p1 = (float)v[k + 1] * a[k + 1] + b[k + 1];
+                if (r >= 1 && s >= 1) bits |= ((p0 > 0.f ? 1u : 0u) << k) | ((p1 > 0.f ? 1u : 0u) << (k + 1));
+                // bf16(relu(a*u + b)), the value the unfused path would have stored (+0 where inactive)
+                const bf16x2 pk = {(bf16)(p0 > 0.f ? p0 : 0.f), (bf16)(p1 > 0.f ? p1 : 0.f)};
+                const uint32_t w2 = __builtin_bit_cast(uint32_t, pk);
+                key[k] = max(key[k], (w2 << 16) | code);
+                key[k + 1] = max(key[k + 1], (w2 & 0xffff0000u) | code);
             }
-            any = true;
             if (r >= 1 && s >= 1)  // this window owns pixel (2ho + r - 1, 2wo + s - 1)
                 mask[(uint32_t)((((int)bb * g.H + hi) * g.W + wi)) * (uint32_t)m.G + m.cg] = (uint8_t)bits;
         }
     }
     const uint32_t off = p * (uint32_t)g.C + m.cg * 8;
-    bf16x8 o;
-    uint64_t packed = 0;
+    uint32_t ow[4], plo = 0, phi = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        o[k] = (bf16)best[k];
-        packed |= (uint64_t)arg[k] << (8 * k);
+    for (int k = 0; k < 8; k += 2) ow[k >> 1] = (key[k] >> 16) | (key[k + 1] & 0xffff0000u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        plo |= (8u - (key[k] & 0xfu)) << (8 * k);
+        phi |= (8u - (key[4 + k] & 0xfu)) << (8 * k);
     }
-    *reinterpret_cast<bf16x8*>(y + off) = o;
-    *reinterpret_cast<uint64_t*>(argmax + off) = packed;
+    *reinterpret_cast<uint4*>(y + off) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    *reinterpret_cast<uint2*>(argmax + off) = make_uint2(plo, phi);
 }
 
 int grid_for(long M, int C) {
