@@ -209,19 +209,20 @@ __global__ __launch_bounds__(256) void k_multi_sgd(const int64_t* __restrict__ t
 // f32 NCHW -> bf16 NHWC through an LDS tile so both sides move full lines.
 // block = (b, h) row: tile [C][W] read coalesced along W, written coalesced along C.
 __global__ __launch_bounds__(256) void k_nchw_f32_to_nhwc_bf16(const float* __restrict__ src, bf16* __restrict__ dst,
-                                                               int C, int H, int W, float scale) {
+                                                               int C, int H, int W, float scale, FastDiv div_c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = reinterpret_cast<float*>(smem);  // [C][W+1]
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int pitch = W + 1;
-    for (int i = threadIdx.x; i < C * W; i += blockDim.x) {
-        const int c = i / W, w = i % W;
-        tile[c * pitch + w] = src[(((long)b * C + c) * H + h) * W + w] * scale;
+    // (no per-element '/' and '%' by runtime values: they cost more than the 12 bytes an element moves)
+    for (int c = 0; c < C; ++c) {
+        const float* row = src + (((long)b * C + c) * H + h) * W;
+        for (int w = threadIdx.x; w < W; w += blockDim.x) tile[c * pitch + w] = row[w] * scale;
     }
     __syncthreads();
     bf16* out = dst + ((long)b * H + h) * W * C;
     for (int i = threadIdx.x; i < C * W; i += blockDim.x) {
-        const int w = i / C, c = i % C;
+        const int w = (int)fdiv((uint32_t)i, div_c), c = i - w * C;
         out[i] = (bf16)tile[c * pitch + w];
     }
 }
@@ -371,7 +372,7 @@ void launch_to_nhwc_bf16(const void* src, int src_dtype, void* dst, int B, int C
     if (src_dtype == kF32) {
         const size_t lds = (size_t)C * (W + 1) * sizeof(float);
         hipLaunchKernelGGL(k_nchw_f32_to_nhwc_bf16, dim3(B * H), dim3(256), lds, s, (const float*)src, (bf16*)dst, C,
-                           H, W, scale);
+                           H, W, scale, make_fastdiv((uint32_t)C));
     } else {
         const long n = (long)B * C * H * W;
         const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
