@@ -276,30 +276,11 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     const bool odd = lane & 1;
     const bool bnr = g.bnr_x != nullptr;               // fused BN-backward reduction (data-gradient launches)
     const bool fwd_stats = stats_slab != nullptr && !bnr;
-    // bnr: fetch this thread's rows of the BN input and mask NOW, so their latency hides behind the LDS staging of
-    // the output tile instead of sitting in the store loop
     constexpr int CH = BN / 8;          // 16-B chunks per output row
     constexpr int ORPP = 256 / CH;      // output rows per pass
     constexpr int NPASS = BM / ORPP;
-    constexpr bool PREFETCH = NPASS <= 8 && MINW < 4;  // taller tiles (and the 128-register build) keep their registers and load in the loop
-    constexpr int NPF = PREFETCH ? NPASS : 1;
     const int orow = tid / CH, och = tid % CH;
     const int ncol = tile_n * BN + och * 8;
-    bf16x8 bx[NPF];
-    unsigned bbits[NPF];
-    if (bnr && PREFETCH) {
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            const long m = (long)tile_m * BM + p * ORPP + orow;  // bnr launches are dense stride-1: pixel == m
-            bbits[p] = 0u;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) bx[p][k] = (bf16)0.f;
-            if (m < M && ncol < g.N) {
-                bx[p] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.bnr_x) + m * g.N + ncol);
-                bbits[p] = g.bnr_mask[(m * g.N + ncol) >> 3];
-            }
-        }
-    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         // Lanes l and l^1 hold columns (n, n+1) of the same rows r, r+1: one DPP exchange (a VALU move, no LDS
@@ -358,6 +339,51 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     }
 
     const bool dense = (g.os == 1 && g.nOH == g.Hout && g.nOW == g.Wout);
+    // Everything the store loop reads from global memory (the addend with its gate, the BN input and mask of the
+    // fused reduction) is fetched HERE for all passes at once: the accumulators are in LDS by now, so their
+    // registers are free, and the thread has 2 * NPASS independent 16-B loads in flight instead of a
+    // load -> use round trip per pass (these launches move 3-4 activation-sized tensors with a K loop of two
+    // steps: they are streaming kernels and were latency-bound at ~3 TB/s).  Both extras only exist on dense
+    // stride-1 launches, where pixel == m.
+    constexpr bool PREFETCH = NPASS <= 8;  // (the 256-row tile would need 2 x 16 x 4 registers: loads stay in the loop)
+    constexpr int NPF = PREFETCH ? NPASS : 1;
+    const bool has_add = g.addend != nullptr;
+    bf16x8 bx[NPF], ad[NPF];
+    unsigned bbits[NPF], abits[NPF];
+    if (PREFETCH && (bnr || has_add)) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const long m = (long)tile_m * BM + p * ORPP + orow;
+            bbits[p] = 0u;
+            abits[p] = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                bx[p][k] = (bf16)0.f;
+                ad[p][k] = (bf16)0.f;
+            }
+            if (m < M && ncol < g.N) {
+                if (bnr) {
+                    bx[p] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.bnr_x) + m * g.N + ncol);
+                    bbits[p] = g.bnr_mask[(m * g.N + ncol) >> 3];
+                }
+                if (has_add && g.addend_stride == 2) {
+                    // compact stride-2 addend: only even (h, w) receive a term
+                    const int w_ = (int)(m % g.Wout);
+                    const long t_ = m / g.Wout;
+                    const int h_ = (int)(t_ % g.Hout);
+                    if (((w_ | h_) & 1) == 0) {
+                        const long b_ = t_ / g.Hout;
+                        const long cp = (b_ * ((g.Hout + 1) >> 1) + (h_ >> 1)) * ((g.Wout + 1) >> 1) + (w_ >> 1);
+                        ad[p] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.addend) + cp * g.N + ncol);
+                        abits[p] = 0xffu;
+                    }
+                } else if (has_add) {
+                    ad[p] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.addend) + m * g.N + ncol);
+                    abits[p] = g.addend_mask != nullptr ? g.addend_mask[(m * g.N + ncol) >> 3] : 0xffu;
+                }
+            }
+        }
+    }
     float r0[8], r1[8], mu[8], is[8];  // bnr: this thread's 8 channels, summed over the rows it stores
     if (bnr) {
 #pragma unroll
@@ -384,7 +410,13 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                 pix = (b * g.Hout + (i * g.os + g.ooh)) * g.Wout + (j * g.os + g.oow);
             }
             bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * OPITCH + och * 16);
-            if (g.addend != nullptr && g.addend_stride == 2) {
+            if constexpr (PREFETCH) {
+                if (has_add) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        v[k] = (bf16)((float)v[k] + (((abits[p] >> k) & 1u) ? (float)ad[p][k] : 0.f));
+                }
+            } else if (g.addend != nullptr && g.addend_stride == 2) {
                 // compact stride-2 addend (dense stride-1 launch: pix == m): only even (h, w) receive a term
                 const int w_ = (int)(m % g.Wout);
                 const long t_ = m / g.Wout;
@@ -489,11 +521,10 @@ void launch_cfg(const void* x, const void* w, void* y, const ConvGeom& g, float*
                        (const bf16*)w, (bf16*)y, g, stats_slab, m_tiles, n_tiles, xb, wb, xcd_group_tiles(g, n_tiles));
 }
 
-// A/B knob: fused-BN-reduce data gradients on the 128-register build too (its epilogue then loads x / mask inside
-// the store loop instead of prefetching them)
-bool bnr_lean() {
+// A/B knob: PDT_IGEMM_BNR_FAT=1 keeps the fused-BN-reduce data gradients off the 128-register build
+bool bnr_fat() {
     static const bool v = [] {
-        const char* e = std::getenv("PDT_IGEMM_BNR_LEAN");
+        const char* e = std::getenv("PDT_IGEMM_BNR_FAT");
         return e && e[0] == '1';
     }();
     return v;
@@ -612,7 +643,7 @@ void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g,
             // 3x3 takes the 128-register ring of 3 (-4 %).
             if (use_tall_tile(g)) {
                 launch_cfg<256, 128, 2, 2, 32, 2, 3>(x, w, y, g, stats_slab, s);
-            } else if ((long)g.ntaps * g.C <= 512 && (g.bnr_x == nullptr || bnr_lean())) {
+            } else if ((long)g.ntaps * g.C <= 512 && (g.bnr_x == nullptr || !bnr_fat())) {
                 if (n128) launch_cfg<128, 128, 2, 2, 32, 4, 2>(x, w, y, g, stats_slab, s);
                 else launch_cfg<128, 64, 4, 1, 32, 4, 2>(x, w, y, g, stats_slab, s);
             } else if (g.ntaps > 1 && g.C == 64) {
