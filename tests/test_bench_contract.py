@@ -1,0 +1,68 @@
+"""bench.py under the round driver's command line (CPU rehearsal with gloo, world size 1 and 2).
+
+The driver launches ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port P bench.py --gpus N --steps K --warmup W`` and reads ONE JSON line from rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config"}
+SMALL = ["--backend", "gloo", "--model", "resnet18", "--batch_size", "2", "--image_size", "32", "--num_classes", "10",
+         "--dtype", "fp32", "--steps", "2", "--warmup", "1"]
+
+
+def _json_lines(out: str):
+    rows = []
+    for line in out.splitlines():
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            rows.append(json.loads(line))
+    return rows
+
+
+def _env():
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["PDT_FORCE_REFERENCE_OPS"] = "1"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_single_process_prints_one_json_line():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *SMALL], cwd=ROOT, env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows = _json_lines(p.stdout)
+    assert len(rows) == 1
+    r = rows[0]
+    assert KEYS <= set(r) and r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["data"] == "synthetic"
+    assert r["config"]["global_batch"] == 2 and r["config"]["parallelism"] == "dp1"
+    assert abs(r["value"] - r["config"]["global_batch"] / (r["ms_per_step"] / 1e3)) / r["value"] < 1e-2
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_under_torch_distributed_run(free_port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL]
+    p = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=540)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows = _json_lines(p.stdout)
+    assert len(rows) == 1, p.stdout[-2000:]  # rank 0 only
+    r = rows[0]
+    assert KEYS <= set(r) and r["n_gpus"] == 2
+    assert r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2"  # value is the whole job's
+    assert abs(r["value"] - 4 / (r["ms_per_step"] / 1e3)) / r["value"] < 1e-2
+
+
+def test_gpus_flag_must_match_world_size(free_port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port), os.path.join(ROOT, "bench.py"), "--gpus", "4", *SMALL]
+    p = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
