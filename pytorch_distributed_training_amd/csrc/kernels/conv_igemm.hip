@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     // load -> use round trip per pass (these launches move 3-4 activation-sized tensors with a K loop of two
     // steps: they are streaming kernels and were latency-bound at ~3 TB/s).  Both extras only exist on dense
     // stride-1 launches, where pixel == m.
-    constexpr bool PREFETCH = NPASS <= 8;  // (the 256-row tile would need 2 x 16 x 4 registers: loads stay in the loop)
+    constexpr bool PREFETCH = NPASS <= 16;  // (the 256-row tile: 2 x 16 x 4 registers, which its 2-workgroups-per-CU budget has once the accumulators are staged)
     constexpr int NPF = PREFETCH ? NPASS : 1;
     const bool has_add = g.addend != nullptr;
     bf16x8 bx[NPF], ad[NPF];
