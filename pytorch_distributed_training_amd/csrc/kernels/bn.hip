@@ -109,7 +109,22 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restric
     const int c = blockIdx.x * 32 + cl;
     float s = 0.f, q = 0.f;
     if (c < C) {
-        for (int p = rl; p < nparts; p += 8) {
+        // (four rows per trip with their loads issued first; same summation order as row by row)
+        int p = rl;
+        for (; p + 24 < nparts; p += 32) {
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = stats[(long)(p + 8 * u) * 2 * C + c];
+                b[u] = stats[(long)(p + 8 * u) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += a[u];
+                q += b[u];
+            }
+        }
+        for (; p < nparts; p += 8) {
             s += stats[(long)p * 2 * C + c];
             q += stats[(long)p * 2 * C + C + c];
         }

@@ -294,7 +294,19 @@ __global__ __launch_bounds__(256) void k_reduce_slab(const float* __restrict__ s
     const int p1 = min(nparts, p0 + parts_per_chunk);
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     if (j < n) {
-        for (int p = p0 + rl; p < p1; p += 4) {
+        // eight rows per trip, all loads issued before the first add (same summation order as one row at a time:
+        // a runtime-count loop of load -> add pays one memory round trip per row)
+        int p = p0 + rl;
+        for (; p + 28 < p1; p += 32) {
+            float v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) load4<float>(slab + (long)(p + 4 * u) * stride, j, n, v[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] += v[u][k];
+        }
+        for (; p < p1; p += 4) {
             float v[4];
             load4<float>(slab + (long)p * stride, j, n, v);
 #pragma unroll
