@@ -93,10 +93,11 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
     for (int p = 0; p < PA; ++p) {
         const long m = (long)tile_m * BM + p * RPP + lrow;
         if (m < M) {
-            const int j = (int)(m % g.nOW);
-            const long t1 = m / g.nOW;
-            const int i = (int)(t1 % g.nOH);
-            const int b = (int)(t1 / g.nOH);
+            const uint32_t t1 = fdiv((uint32_t)m, g.div_now);
+            const int j = (int)((uint32_t)m - t1 * (uint32_t)g.nOW);
+            const uint32_t bq = fdiv(t1, g.div_noh);
+            const int i = (int)(t1 - bq * (uint32_t)g.nOH);
+            const int b = (int)bq;
             rowpix[p] = b * g.Hin * g.Win;
             rih[p] = i * g.is;
             riw[p] = j * g.is;
@@ -368,11 +369,12 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                 }
                 if (has_add && g.addend_stride == 2) {
                     // compact stride-2 addend: only even (h, w) receive a term
-                    const int w_ = (int)(m % g.Wout);
-                    const long t_ = m / g.Wout;
-                    const int h_ = (int)(t_ % g.Hout);
+                    const uint32_t t_ = fdiv((uint32_t)m, g.div_wout);
+                    const int w_ = (int)((uint32_t)m - t_ * (uint32_t)g.Wout);
+                    const uint32_t bq_ = fdiv(t_, g.div_hout);
+                    const int h_ = (int)(t_ - bq_ * (uint32_t)g.Hout);
                     if (((w_ | h_) & 1) == 0) {
-                        const long b_ = t_ / g.Hout;
+                        const long b_ = (long)bq_;
                         const long cp = (b_ * ((g.Hout + 1) >> 1) + (h_ >> 1)) * ((g.Wout + 1) >> 1) + (w_ >> 1);
                         ad[p] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.addend) + cp * g.N + ncol);
                         abits[p] = 0xffu;
@@ -403,10 +405,11 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
             if (dense) {
                 pix = m;
             } else {
-                const int j = (int)(m % g.nOW);
-                const long t1 = m / g.nOW;
-                const int i = (int)(t1 % g.nOH);
-                const long b = t1 / g.nOH;
+                const uint32_t t1 = fdiv((uint32_t)m, g.div_now);
+                const int j = (int)((uint32_t)m - t1 * (uint32_t)g.nOW);
+                const uint32_t bq = fdiv(t1, g.div_noh);
+                const int i = (int)(t1 - bq * (uint32_t)g.nOH);
+                const long b = (long)bq;
                 pix = (b * g.Hout + (i * g.os + g.ooh)) * g.Wout + (j * g.os + g.oow);
             }
             bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * OPITCH + och * 16);
@@ -418,11 +421,12 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                 }
             } else if (g.addend != nullptr && g.addend_stride == 2) {
                 // compact stride-2 addend (dense stride-1 launch: pix == m): only even (h, w) receive a term
-                const int w_ = (int)(m % g.Wout);
-                const long t_ = m / g.Wout;
-                const int h_ = (int)(t_ % g.Hout);
+                const uint32_t t_ = fdiv((uint32_t)m, g.div_wout);
+                const int w_ = (int)((uint32_t)m - t_ * (uint32_t)g.Wout);
+                const uint32_t bq_ = fdiv(t_, g.div_hout);
+                const int h_ = (int)(t_ - bq_ * (uint32_t)g.Hout);
                 if (((w_ | h_) & 1) == 0) {
-                    const long b_ = t_ / g.Hout;
+                    const long b_ = (long)bq_;
                     const long cp = (b_ * ((g.Hout + 1) >> 1) + (h_ >> 1)) * ((g.Wout + 1) >> 1) + (w_ >> 1);
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.addend) + cp * g.N + ncol);
 #pragma unroll
@@ -517,8 +521,17 @@ void launch_cfg(const void* x, const void* w, void* y, const ConvGeom& g, float*
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    ConvGeom gd = g;
+    gd.div_now = make_fastdiv((uint32_t)g.nOW);
+    gd.div_noh = make_fastdiv((uint32_t)g.nOH);
+    gd.div_wout = make_fastdiv((uint32_t)g.Wout);
+    gd.div_hout = make_fastdiv((uint32_t)g.Hout);
+    if (M >= (1L << 31)) {
+        fprintf(stderr, "conv_igemm: %ld output pixels exceed the 31-bit index space\n", M);
+        abort();
+    }
     hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, BK, MINW, NS>), dim3(m_tiles * n_tiles), dim3(256), lds, s, (const bf16*)x,
-                       (const bf16*)w, (bf16*)y, g, stats_slab, m_tiles, n_tiles, xb, wb, xcd_group_tiles(g, n_tiles));
+                       (const bf16*)w, (bf16*)y, gd, stats_slab, m_tiles, n_tiles, xb, wb, xcd_group_tiles(g, n_tiles));
 }
 
 // A/B knob: PDT_IGEMM_BNR_FAT=1 keeps the fused-BN-reduce data gradients off the 128-register build

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fastdiv.h"
+
 namespace pdt {
 
 enum DType : int { kF32 = 0, kBF16 = 1, kU8 = 2 };
@@ -143,6 +145,10 @@ struct ConvGeom {
     // (the downsample branch): shape [B, ceil(Hout/2), ceil(Wout/2), N], added at the even (h, w) positions only.
     // Saves zero-filling a full-size tensor and reading it back (3/4 of it zeros).
     int addend_stride;
+    // multiply-shift dividers for the pixel decompositions m -> (b, i, j) (filled by launch_conv_igemm): by nOW, nOH,
+    // Wout, Hout.  64-bit '/' and '%' by runtime values cost ~40 vector instructions each; a short-K launch did
+    // eight of them per thread in its prologue and up to 32 in its epilogue.
+    FastDiv div_now, div_noh, div_wout, div_hout;
     // elements per input pixel in memory; 0 = C (dense NHWC).  The packed stem runs with C = 32 (one filter
     // row: 8 kw slots x 4 channels, contiguous in memory) over pixels of 4 elements.
     int pix_elems;
