@@ -566,14 +566,22 @@ bool use_tall_tile(const ConvGeom& g) {
     const long M = (long)g.B * g.nOH * g.nOW;
     return g.N % 128 == 0 && g.C % 64 == 0 && (long)g.ntaps * g.C >= 1024 && (M / 256) * (g.N / 128) >= 256;
 }
+// 64-wide outputs: a 256x64 tile (each wave 64x64) reads 1 instead of 1.5 LDS fragments per MFMA and stages the
+// weights half as often; B=1024: 64-channel 3x3 484 -> 453 us, 256->64 pointwise forward 411 -> 373 us, a loss on
+// K = 64 (nothing to amortise)
+bool use_tall64(const ConvGeom& g) {
+    const long M = (long)g.B * g.nOH * g.nOW;
+    return g.N % 128 != 0 && (g.C % 64 == 0 || g.C == 32) && (long)g.ntaps * g.C >= 224 && M / 256 >= 512;
+}
 // rows of the output tile the launch heuristic below picks for this geometry (the slab of per-m-tile partial
 // rows the bindings allocate has one row per tile)
 int igemm_bm(const ConvGeom& g) {
     const int cfg = igemm_cfg_override();
     const bool n128 = g.N % 128 == 0;
     if (cfg == 10) return n128 ? 256 : 128;
+    if (cfg == 15) return n128 ? 128 : 256;
     if (cfg != 0) return 128;
-    return use_tall_tile(g) ? 256 : 128;
+    return (use_tall_tile(g) || use_tall64(g)) ? 256 : 128;
 }
 }  // namespace
 
@@ -589,6 +597,7 @@ void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g,
     const bool n128 = g.N % 128 == 0;
     if (g.C % 64 != 0) {  // 32-channel K rows (the packed stem): only the BK = 32 tiles apply
         if (n128) launch_cfg<128, 128, 2, 2, 32, 3, 3>(x, w, y, g, stats_slab, s);
+        else if (igemm_bm(g) == 256) launch_cfg<256, 64, 4, 1, 32, 2, 3>(x, w, y, g, stats_slab, s);
         else launch_cfg<128, 64, 4, 1, 32, 3, 3>(x, w, y, g, stats_slab, s);
         return;
     }
@@ -609,6 +618,10 @@ void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g,
         case 10:  // LDS-DMA ring, 256x128 tile (each wave 128x64), BK=32, 3 stages (72 KB: two workgroups per CU)
             if (n128) launch_cfg<256, 128, 2, 2, 32, 2, 3>(x, w, y, g, stats_slab, s);
             else launch_cfg<128, 64, 4, 1, 32, 3, 3>(x, w, y, g, stats_slab, s);
+            return;
+        case 15:  // 256x64 tile for 64-wide outputs (each wave 64x64: 1 instead of 1.5 fragment reads per MFMA)
+            if (n128) launch_cfg<128, 128, 2, 2, 32, 3, 3>(x, w, y, g, stats_slab, s);
+            else launch_cfg<256, 64, 4, 1, 32, 2, 3>(x, w, y, g, stats_slab, s);
             return;
         case 11:  // double-buffered DMA (2 stages), 128-register build: four workgroups per CU for short-K layers
             if (n128) launch_cfg<128, 128, 2, 2, 32, 4, 2>(x, w, y, g, stats_slab, s);
@@ -656,6 +669,8 @@ void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g,
             // 3x3 takes the 128-register ring of 3 (-4 %).
             if (use_tall_tile(g)) {
                 launch_cfg<256, 128, 2, 2, 32, 2, 3>(x, w, y, g, stats_slab, s);
+            } else if (use_tall64(g)) {
+                launch_cfg<256, 64, 4, 1, 32, 2, 3>(x, w, y, g, stats_slab, s);
             } else if ((long)g.ntaps * g.C <= 512 && (g.bnr_x == nullptr || !bnr_fat())) {
                 if (n128) launch_cfg<128, 128, 2, 2, 32, 4, 2>(x, w, y, g, stats_slab, s);
                 else launch_cfg<128, 64, 4, 1, 32, 4, 2>(x, w, y, g, stats_slab, s);
