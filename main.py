@@ -103,6 +103,9 @@ def main(argv=None) -> int:
             model=args.model, num_classes=args.num_classes, dtype=args.dtype, optimizer=args.optimizer, lr=args.lr,
             momentum=args.momentum, weight_decay=args.weight_decay, sync_bn=args.sync_bn,
             bucket_cap_mb=args.bucket_cap_mb, seed=args.seed, graph=args.graph,
+            # the torch profiler's one cycle (wait 2 + warmup 2 + active 6) ends at step 10: capture after it, so
+            # that the trace shows real kernels and no collection is active while the stream is being captured
+            graph_warmup=12 if args.profile == "torch" else 3,
             image_size=trainset.sample_shape[1]))
         start_epoch, global_step = 0, 0
         if args.resume:
