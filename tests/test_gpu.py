@@ -207,6 +207,58 @@ def test_bf16_native_matches_oracles(model):
     print(f"{model}: worst gradient cosine vs fp32: library-bf16 {worst_b:.4f}, native {worst_c:.4f}")
 
 
+def test_dataflow_fusions_do_not_change_the_native_result(monkeypatch):
+    """Gated residual gradient, deferred downsample BN, compact downsample gradient, fused stem tail and the
+    BN-reduce-in-dgrad epilogue only re-arrange WHERE things are computed.  Switching each off on the native path:
+    the forward is bit-identical for all but the deferred downsample BN (which adds its branch in fp32 instead of
+    as a bf16-rounded tensor), and the gradients agree up to the rounding of the intermediates that the fusion
+    keeps in fp32.  A 14-layer bottleneck net is used: the 50-layer one at random init amplifies ONE bf16 rounding
+    difference (or the run-to-run order of MIOpen's atomics) into ~10 % of the logits
+    (bench/micro/fusion_ab.py prints both)."""
+    import pytorch_distributed_training_amd.models.resnet as R
+    import pytorch_distributed_training_amd.nn.functional as F
+    from pytorch_distributed_training_amd import nn as pnn
+    from pytorch_distributed_training_amd.parallel import ParamArena
+
+    torch.manual_seed(0)
+    net = R.ResNet(R.Bottleneck, [1, 1, 1, 1], num_classes=10).cuda()
+    arena = ParamArena(net)
+    arena.attach_lowp(torch.bfloat16)
+    x = torch.randn(32, 3, 64, 64, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, 10, (32,), device="cuda")
+    crit = pnn.CrossEntropyLoss()
+    knobs = [(R, "_LAZY_RES"), (R, "_DEFER_DS"), (R, "_COMPACT_DS"), (F, "_FUSE_STEM_POOL"), (F, "_FUSE_BN_REDUCE")]
+
+    def run(off=()):
+        for mod, n in knobs:
+            monkeypatch.setattr(mod, n, n not in off)
+        for p in net.parameters():
+            p.grad = None
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.reset_running_stats()
+        out = net(x)
+        crit(out, y).backward()
+        return out.detach().float(), {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
+
+    def compare(a, b):
+        (o1, g1), (o0, g0) = a, b
+        err = float((o1 - o0).abs().max() / o0.abs().max())
+        cos = min(float(torch.dot(g1[n].flatten(), g0[n].flatten()) / (g1[n].norm() * g0[n].norm() + 1e-12)) for n in g0)
+        return err, cos
+
+    base = run()
+    assert not F.fallback_counts, dict(F.fallback_counts)
+    assert compare(run(), base) == (0.0, pytest.approx(1.0, abs=1e-5))  # the native path is deterministic
+    for _, name in knobs:
+        err, cos = compare(run((name,)), base)
+        print(f"{name} off: logits rel err {err:.4f}, worst gradient cosine {cos:.4f}")
+        if name == "_DEFER_DS":
+            assert err < 0.05 and cos > 0.9, (name, err, cos)
+        else:
+            assert err == 0.0 and cos > 0.99, (name, err, cos)
+
+
 def test_reducer_runs_the_rccl_path_with_a_size1_communicator(tmp_path):
     """The multi-GPU hot path (multi-tensor flatten -> fence -> ncclAllReduce on the communicator's stream ->
     per-bucket event -> optimizer) on one GPU: PDT_FORCE_COMM=1 gives the C++ reducer a size-1 communicator, and
