@@ -135,6 +135,7 @@ def main(argv=None) -> int:
                 "backend": env.backend, "baseline_images_per_sec": round(base, 1),
                 "library_fallbacks": dict(pF.fallback_counts), "final_loss": final_loss,
                 "hip_graph": bool(engine._graph is not None), "batch_model": batch_model, "bucket_autotune": engine.net.bucket_autotune,
+                "sync_bn_comm": engine.sync_bn_comm,
             },
         }
         print(json.dumps(out), flush=True)

@@ -2,6 +2,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
 
+#include "../comm/ipc_allreduce.h"
 #include "../comm/rccl_comm.h"
 #include "../reducer/reducer.h"
 #include "binding.h"
@@ -53,6 +54,28 @@ PYBIND11_MODULE(_C, m) {
         .def("synchronize", &pdt::RcclComm::synchronize, py::call_guard<py::gil_scoped_release>())
         .def("async_error", &pdt::RcclComm::async_error)
         .def("abort", &pdt::RcclComm::abort);
+
+    py::class_<pdt::IpcAllReduce, std::shared_ptr<pdt::IpcAllReduce>>(m, "IpcAllReduce")
+        .def(py::init([](int rank, int world, int device, int cap, double timeout_s) {
+                 return std::make_shared<pdt::IpcAllReduce>(rank, world, device, cap, timeout_s);
+             }),
+             py::arg("rank"), py::arg("world_size"), py::arg("device"), py::arg("capacity") = 16384,
+             py::arg("timeout_s") = 30.0)
+        .def("handle", [](pdt::IpcAllReduce& c) { return py::bytes(c.handle()); })
+        .def("open_peers", [](pdt::IpcAllReduce& c, std::vector<std::string> handles) { c.open_peers(handles); })
+        .def_property_readonly("ready", &pdt::IpcAllReduce::ready)
+        .def_property_readonly("capacity", &pdt::IpcAllReduce::cap)
+        .def_property_readonly("world_size", &pdt::IpcAllReduce::world_size)
+        .def("timed_out", &pdt::IpcAllReduce::timed_out)
+        .def("clear_error", &pdt::IpcAllReduce::clear_error)
+        .def("set_timeout", &pdt::IpcAllReduce::set_timeout)
+        // in-place sum over the ranks of a contiguous fp32 GPU tensor, one kernel on the current stream
+        .def("all_reduce_", [](pdt::IpcAllReduce& c, at::Tensor t) {
+            TORCH_CHECK(t.is_cuda() && t.is_contiguous() && t.scalar_type() == at::kFloat,
+                        "IpcAllReduce takes a contiguous fp32 GPU tensor");
+            hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
+            c.all_reduce(t.data_ptr<float>(), t.numel(), cur);
+        });
 
     py::class_<pdt::Reducer, std::shared_ptr<pdt::Reducer>>(m, "Reducer")
         .def(py::init([](std::vector<at::Tensor> params, std::vector<std::string> names,

@@ -1,0 +1,94 @@
+#include "ipc_allreduce.h"
+
+#include <c10/util/Exception.h>
+
+#include <cstdlib>
+#include <cstring>
+
+namespace pdt {
+
+#define PDT_HIP(expr)                                                                \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        TORCH_CHECK(_e == hipSuccess, "HIP error: ", hipGetErrorString(_e), " (" #expr ")"); \
+    } while (0)
+
+IpcAllReduce::IpcAllReduce(int rank, int world, int device, int cap_elems, double timeout_s) : device_(device) {
+    TORCH_CHECK(world >= 1 && world <= kIpcMaxRanks, "IpcAllReduce: world size ", world, " outside [1, ", kIpcMaxRanks, "]");
+    TORCH_CHECK(rank >= 0 && rank < world, "IpcAllReduce: bad rank");
+    TORCH_CHECK(cap_elems > 0 && cap_elems <= (1 << 20), "IpcAllReduce: bad capacity");
+    PDT_HIP(hipSetDevice(device));
+    mb_.rank = rank;
+    mb_.world = world;
+    mb_.cap = cap_elems;
+    mb_.timeout_ticks = (long long)(timeout_s * 100e6);  // wall_clock64 runs at 100 MHz
+    bytes_ = (size_t)2 * world * cap_elems * sizeof(uint64_t);
+    // Peers store into this buffer over xGMI while the local kernel polls it: it must not be held in a
+    // non-coherent cache.  PDT_IPC_MEM selects the allocation flavour for experiments on other hosts.
+    const char* flavour = std::getenv("PDT_IPC_MEM");
+    const std::string fl = flavour ? flavour : "uncached";
+    void* base = nullptr;
+    if (fl == "plain") {
+        PDT_HIP(hipMalloc(&base, bytes_));
+    } else {
+        PDT_HIP(hipExtMallocWithFlags(&base, bytes_, fl == "finegrained" ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
+    }
+    PDT_HIP(hipMemset(base, 0, bytes_));
+    for (auto& m : mb_.mail) m = nullptr;
+    mb_.mail[rank] = static_cast<uint64_t*>(base);
+    PDT_HIP(hipMalloc(reinterpret_cast<void**>(&mb_.seq), sizeof(uint32_t)));
+    PDT_HIP(hipMemset(mb_.seq, 0, sizeof(uint32_t)));
+    void* hs = nullptr;
+    PDT_HIP(hipHostMalloc(&hs, sizeof(uint32_t), hipHostMallocMapped));
+    host_status_ = static_cast<volatile uint32_t*>(hs);
+    *host_status_ = 0;
+    void* ds = nullptr;
+    PDT_HIP(hipHostGetDevicePointer(&ds, hs, 0));
+    mb_.status = static_cast<uint32_t*>(ds);
+    PDT_HIP(hipDeviceSynchronize());
+    if (world > 1) PDT_HIP(hipIpcGetMemHandle(&handle_, base));
+    ready_ = world == 1;
+}
+
+IpcAllReduce::~IpcAllReduce() {
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    for (void* p : opened_) (void)hipIpcCloseMemHandle(p);
+    if (mb_.mail[mb_.rank]) (void)hipFree(mb_.mail[mb_.rank]);
+    if (mb_.seq) (void)hipFree(mb_.seq);
+    if (host_status_) (void)hipHostFree(const_cast<uint32_t*>(host_status_));
+}
+
+std::string IpcAllReduce::handle() const {
+    return std::string(reinterpret_cast<const char*>(&handle_), sizeof(handle_));
+}
+
+void IpcAllReduce::open_peers(const std::vector<std::string>& h) {
+    TORCH_CHECK((int)h.size() == mb_.world, "IpcAllReduce: expected ", mb_.world, " handles, got ", h.size());
+    TORCH_CHECK(!ready_ || mb_.world == 1, "IpcAllReduce: peers already opened");
+    PDT_HIP(hipSetDevice(device_));
+    for (int p = 0; p < mb_.world; ++p) {
+        if (p == mb_.rank) continue;
+        TORCH_CHECK(h[p].size() == sizeof(hipIpcMemHandle_t), "IpcAllReduce: bad handle size from rank ", p);
+        hipIpcMemHandle_t hd;
+        std::memcpy(&hd, h[p].data(), sizeof(hd));
+        void* ptr = nullptr;
+        PDT_HIP(hipIpcOpenMemHandle(&ptr, hd, hipIpcMemLazyEnablePeerAccess));
+        opened_.push_back(ptr);
+        mb_.mail[p] = static_cast<uint64_t*>(ptr);
+    }
+    ready_ = true;
+}
+
+void IpcAllReduce::clear_error() {
+    if (host_status_) *host_status_ = 0;
+}
+
+void IpcAllReduce::all_reduce(float* data, int64_t n, hipStream_t s) {
+    TORCH_CHECK(ready_, "IpcAllReduce: open_peers() has not run");
+    TORCH_CHECK(n >= 0 && n <= mb_.cap, "IpcAllReduce: ", n, " elements exceed the mailbox capacity ", mb_.cap);
+    TORCH_CHECK(!timed_out(), "IpcAllReduce: an earlier all-reduce ran out of time waiting for a peer");
+    launch_ipc_allreduce(data, (int)n, mb_, s);
+}
+
+}  // namespace pdt

@@ -68,8 +68,15 @@ class Engine:
         self.criterion = pnn.CrossEntropyLoss()
         self.optimizer = build_optimizer(cfg.optimizer, net.parameters(), cfg.lr, cfg.momentum, cfg.weight_decay)
         net = net.to(self.device)
+        self.sync_bn_comm = None
         if cfg.sync_bn:
-            net = pnn.convert_sync_batchnorm(net, process_group=pnn.make_sync_bn_group())
+            sync_group = pnn.make_sync_bn_group()
+            net = pnn.convert_sync_batchnorm(net, process_group=sync_group)
+            if sync_group is not None and self.device.type == "cuda":
+                # decide the statistics all-reduce path now (collective), not inside the first forward
+                from .parallel.ipc import small_all_reduce_path
+
+                self.sync_bn_comm = small_all_reduce_path(sync_group, self.device)[1]
         self.dtype = compute_dtype(cfg, self.device)
         dev_ids = [self.device.index] if self.device.type == "cuda" else None
         self.net = DistributedDataParallel(

@@ -185,6 +185,17 @@ def _sync_world(cfg: BNConfig) -> int:
     return tdist.get_world_size(cfg.group)
 
 
+def _small_all_reduce(t: torch.Tensor, group) -> None:
+    """SUM of a SyncBN statistics vector over the group, on the current stream: the one-kernel IPC path on GPUs
+    that share a host, the process group's all-reduce elsewhere (``parallel/ipc.py``)."""
+    if t.is_cuda:
+        from ..parallel.ipc import small_all_reduce
+
+        small_all_reduce(t, group)
+    else:
+        tdist.all_reduce(t, group=group)
+
+
 class _BNSink:
     """Hand-over between a BN+ReLU node and the conv node that consumes its output.  The conv's data-gradient
     kernel produces exactly the tensor this BN's backward receives as ``dz``; given the BN's saved operands it can
@@ -233,7 +244,7 @@ def _bn_moments(be, x, stats, cfg: BNConfig):
             packed = torch.empty(2 * c + 4, dtype=torch.float32, device=x.device)
             packed[: 2 * c].copy_(be.bn_sum_partials(stats).reshape(-1))
             packed[2 * c:] = count
-            tdist.all_reduce(packed, group=cfg.group)
+            _small_all_reduce(packed, cfg.group)
             stats = packed[: 2 * c].view(1, 2, c)
             count_t = packed[2 * c: 2 * c + 1]
         cnt = count_t if count_t is not None else count
@@ -323,7 +334,7 @@ class _BNActFn(torch.autograd.Function):
             # the affine grads stay local (DDP averages them); the sums that feed grad_input are global
             sums = be.bn_sum_partials(psums)
             gsums = sums.clone()
-            tdist.all_reduce(gsums, group=cfg.group)
+            _small_all_reduce(gsums, cfg.group)
             dx, dres, _ = be.bn_bwd_elemt(dz, z, x, mean, invstd, g32, gsums.view(1, 2, -1), count_t, relu, want_dres)
         elif cfg.training:
             dx, dres, sums = be.bn_bwd_elemt(dz, z, x, mean, invstd, g32, psums, count, relu, want_dres)
@@ -514,7 +525,7 @@ class _BNReluPoolFn(torch.autograd.Function):
         if cfg.training and world > 1:
             sums = be.bn_sum_partials(psums)
             gsums = sums.clone()
-            tdist.all_reduce(gsums, group=cfg.group)
+            _small_all_reduce(gsums, cfg.group)
             du, _, _ = be.bn_bwd_elemt(dz, act, u, mean, invstd, g32, gsums.view(1, 2, -1), count_t, True, False)
         elif cfg.training:
             du, _, sums = be.bn_bwd_elemt(dz, act, u, mean, invstd, g32, psums, count, True, False)

@@ -1,0 +1,213 @@
+"""Latency-path all-reduce for SyncBatchNorm: one kernel over IPC-mapped peer memory.
+
+SURVEY §2.5 S4a/S4b, §5.8 layer 3, §7.4 item 4: SyncBN issues 106 data-dependent
+all-reduces of at most 2C+4 floats per step.  They cannot be overlapped, only made
+cheap.  Through a process-group collective each one costs a launch on RCCL's stream
+plus its proxy hand-shake; ``_C.IpcAllReduce`` (``csrc/comm/ipc_allreduce.*``) does
+the same sum in ONE kernel on the compute stream: every rank stores its values
+straight into the mailboxes of all peers over xGMI and adds what arrived in its own.
+
+``small_all_reduce`` is what ``nn/functional.py`` calls.  Which path it takes is a
+per-group decision made once, collectively, at first use (``PDT_SYNCBN_COMM``):
+
+``auto`` (default)  set the mailboxes up, check the kernel's result against the
+                    process group's on random data, time both, keep the faster one;
+                    any failure on any rank (IPC refused, ranks on different hosts,
+                    mismatch, time-out) sends every rank to the process group.
+``ipc``             same checks, but IPC is used whenever it is correct.
+``torch`` / ``rccl``  the process group's all-reduce (what ``torch.nn.SyncBatchNorm``
+                    does, ``torch/nn/modules/_functions.py:48-77,157-165``).
+"""
+from __future__ import annotations
+
+import os
+import socket
+import time
+
+import torch
+import torch.distributed as tdist
+
+_CAPACITY = 16384  # floats per message (2C+4 at C=2048 is 4100)
+_paths: dict = {}
+
+
+def _ext():
+    from ..utils.env import native
+
+    return native()
+
+
+class IpcSmallAllReduce:
+    """The mailboxes of one process group.  Construction is collective: every rank of ``group`` must call it."""
+
+    def __init__(self, group=None, device: torch.device | None = None, capacity: int = _CAPACITY,
+                 timeout_s: float | None = None):
+        self.group = group
+        self.rank = tdist.get_rank(group)
+        self.world = tdist.get_world_size(group)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.capacity = capacity
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("PDT_IPC_TIMEOUT_S", "30"))
+        self.timeout_s = timeout_s
+        self.native = None
+        err = None
+        handle = None
+        try:
+            ext = _ext()
+            if ext is None or not hasattr(ext, "IpcAllReduce"):
+                raise RuntimeError("native extension not built")
+            self.native = ext.IpcAllReduce(self.rank, self.world, self.device.index or 0, capacity, timeout_s)
+            handle = bytes(self.native.handle())
+        except Exception as e:  # every rank still takes part in the exchange below
+            err = repr(e)
+        mine = (handle, socket.gethostname(), err)
+        everyone = [None] * self.world
+        tdist.all_gather_object(everyone, mine, group=group)
+        if err is None:
+            try:
+                bad = [f"rank {r}: {e[2]}" for r, e in enumerate(everyone) if e[2] is not None]
+                if bad:
+                    raise RuntimeError("; ".join(bad))
+                if len({e[1] for e in everyone}) != 1:
+                    raise RuntimeError("the group spans hosts: peer memory cannot be mapped")
+                self.native.open_peers([e[0] for e in everyone])
+            except Exception as e:
+                err = repr(e)
+        self.error = self._agree(err)
+        if self.error is not None:
+            self.native = None
+
+    def _agree(self, err):
+        """None when every rank is fine, else one rank's message on every rank."""
+        msgs = [None] * self.world
+        tdist.all_gather_object(msgs, err, group=self.group)
+        bad = [f"rank {r}: {m}" for r, m in enumerate(msgs) if m is not None]
+        return "; ".join(bad) if bad else None
+
+    @property
+    def ok(self) -> bool:
+        return self.native is not None
+
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        self.native.all_reduce_(t)
+        return t
+
+    def timed_out(self) -> bool:
+        return self.native is not None and self.native.timed_out()
+
+    def _group_all_reduce(self, t: torch.Tensor) -> None:
+        if t.is_cuda and tdist.get_backend(self.group) == "gloo":  # (tests: a CPU group driving GPU mailboxes)
+            c = t.cpu()
+            tdist.all_reduce(c, group=self.group)
+            t.copy_(c)
+        else:
+            tdist.all_reduce(t, group=self.group)
+
+    # -- collective self-check + timing --------------------------------------------------------------
+    def validate(self, sizes=(132, 1028, 4100), iters: int = 20, check_timeout_s: float = 5.0):
+        """-> (error or None, ipc_us, group_us): compares against the process group's all-reduce on random data
+        and times both.  Collective: every rank runs the same sequence of process-group calls whatever happens
+        to its IPC path, and a rank whose IPC path failed stops using it (its peers then run into the short
+        time limit once and stop as well)."""
+        err = None
+        t_ipc = t_pg = float("inf")
+
+        def note(msg):
+            nonlocal err
+            if err is None:
+                err = msg
+
+        def ipc_call(t):
+            if err is None:
+                try:
+                    self.native.all_reduce_(t)
+                except Exception as e:
+                    note(repr(e))
+            return t
+
+        self.native.set_timeout(check_timeout_s)
+        gen = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        for n in sizes:
+            x = torch.randn(n, generator=gen).to(self.device)
+            want = x.clone()
+            self._group_all_reduce(want)
+            for _ in range(3):  # both mailbox sets, and the same set twice
+                got = ipc_call(x.clone())
+            torch.cuda.synchronize(self.device)
+            if self.native.timed_out():
+                note("a peer did not arrive within the time limit")
+            scale = float(want.abs().max().clamp_min(1e-6))
+            if not bool(((got - want).abs().max() / scale) < 1e-5):
+                note(f"mismatch against the process group at n={n}")
+        x = torch.zeros(sizes[-1], device=self.device)
+        for which in ("ipc", "pg"):
+            fn = (lambda: ipc_call(x)) if which == "ipc" else (lambda: self._group_all_reduce(x))
+            fn()
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize(self.device)
+            dt = (time.perf_counter() - t0) / iters * 1e6
+            if which == "ipc":
+                t_ipc = dt
+            else:
+                t_pg = dt
+        if self.native.timed_out():
+            note("a peer did not arrive within the time limit")
+        err = self._agree(err)
+        if err is None:
+            self.native.set_timeout(self.timeout_s)
+        # rank 0's clock decides, so every rank takes the same path
+        times = [(t_ipc, t_pg)] if self.rank == 0 else [None]
+        src = tdist.get_global_rank(self.group, 0) if self.group is not None else 0
+        tdist.broadcast_object_list(times, src=src, group=self.group)
+        return err, times[0][0], times[0][1]
+
+
+def _decide(group, device):
+    mode = os.environ.get("PDT_SYNCBN_COMM", "auto").lower()
+    info = {"mode": mode, "path": "group", "why": None, "ipc_us": None, "group_us": None}
+    if mode in ("torch", "rccl", "group", "nccl") or device.type != "cuda":
+        info["why"] = "selected" if device.type == "cuda" else "cpu tensors"
+        return None, info
+    ipc = IpcSmallAllReduce(group, device)
+    if not ipc.ok:
+        info["why"] = ipc.error
+        return None, info
+    err, t_ipc, t_pg = ipc.validate()
+    info["ipc_us"], info["group_us"] = t_ipc, t_pg
+    if err is not None:
+        info["why"] = err
+        return None, info
+    if mode == "ipc" or t_ipc <= t_pg:
+        info["path"] = "ipc"
+        return ipc, info
+    info["why"] = "the process group was faster"
+    return None, info
+
+
+def small_all_reduce_path(group, device):
+    """The (cached) decision for ``group``: ``(IpcSmallAllReduce or None, info dict)``.  Collective on first use."""
+    key = (id(group) if group is not None else None, str(device))
+    if key not in _paths:
+        _paths[key] = _decide(group, device)
+        if tdist.get_rank(group) == 0 and os.environ.get("PDT_QUIET", "0") == "0":
+            _, info = _paths[key]
+            print(f"[syncbn-comm] {info}", flush=True)
+    return _paths[key]
+
+
+def small_all_reduce(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM of a small fp32 vector over ``group`` on the current stream."""
+    ipc, _ = small_all_reduce_path(group, t.device)
+    if ipc is not None and t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= ipc.capacity:
+        ipc.all_reduce_(t)
+    else:
+        tdist.all_reduce(t, group=group)
+    return t
+
+
+def reset_paths() -> None:
+    _paths.clear()

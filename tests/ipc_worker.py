@@ -1,0 +1,115 @@
+"""One rank of the IPC small-message all-reduce test (tests/test_gpu.py): W processes that all use GPU 0, a gloo
+group for the bootstrap, ``_C.IpcAllReduce`` mailboxes mapped across the processes with hipIpc handles.
+Prints one JSON line."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as tdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main() -> int:
+    from pytorch_distributed_training_amd import nn as pnn
+    from pytorch_distributed_training_amd.parallel import ipc as pipc
+
+    tdist.init_process_group("gloo")
+    rank, world = tdist.get_rank(), tdist.get_world_size()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    out = {"rank": rank}
+
+    red = pipc.IpcSmallAllReduce(None, dev, timeout_s=10.0)
+    out["setup_error"] = red.error
+    if not red.ok:
+        print(json.dumps(out), flush=True)
+        return 0
+
+    # 1. sums against a CPU all-reduce, several calls back to back (both mailbox sets), identical bits on all ranks
+    gen = torch.Generator().manual_seed(100 + rank)
+    worst, same_bits = 0.0, True
+    for n in (1, 63, 132, 1028, 4100, 16384):
+        for _ in range(4):
+            x = torch.randn(n, generator=gen)
+            want = x.clone()
+            tdist.all_reduce(want)
+            got = red.all_reduce_(x.to(dev)).cpu()
+            worst = max(worst, float((got - want).abs().max() / want.abs().max().clamp_min(1e-6)))
+            everyone = [torch.empty_like(got) for _ in range(world)]
+            tdist.all_gather(everyone, got)
+            same_bits = same_bits and all(torch.equal(e, everyone[0]) for e in everyone)
+    out["worst_rel_err"], out["same_bits"] = worst, same_bits
+
+    # 2. the self-check + timing that decides the path in a job
+    err, t_ipc, t_pg = red.validate(check_timeout_s=5.0)
+    out["validate_error"], out["ipc_us"], out["group_us"] = err, t_ipc, t_pg
+
+    # 3. replayable inside a hipGraph (the sequence number lives in device memory)
+    buf = torch.full((256,), float(rank + 1), device=dev)
+    torch.cuda.synchronize()
+    tdist.barrier()
+    s = torch.cuda.Stream(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        red.all_reduce_(buf)
+    vals = []
+    for _ in range(3):
+        buf.fill_(float(rank + 1))
+        g.replay()
+        torch.cuda.synchronize()
+        vals.append(float(buf[0]))
+    out["graph_vals"] = vals
+    out["graph_want"] = float(sum(range(1, world + 1)))
+
+    # 4. SyncBatchNorm through the IPC path == plain BN over the concatenated batch
+    os.environ["PDT_SYNCBN_COMM"] = "ipc"
+    os.environ["PDT_QUIET"] = "1"
+    torch.manual_seed(0)
+    c, per = 64, 8
+    full = torch.randn(per * world, c, 8, 8).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dfull = torch.randn(per * world, c, 8, 8).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    bn_ref = pnn.BatchNorm2d(c).to(dev)
+    bn_sync = pnn.SyncBatchNorm(c).to(dev)
+    with torch.no_grad():
+        w = torch.rand(c, device=dev) + 0.5
+        b = torch.randn(c, device=dev)
+        for m in (bn_ref, bn_sync):
+            m.weight.copy_(w)
+            m.bias.copy_(b)
+    xr = full.clone().requires_grad_(True)
+    yr = bn_ref(xr, relu=True)
+    yr.backward(dfull)
+    xs = full[rank * per:(rank + 1) * per].clone().requires_grad_(True)
+    ys = bn_sync(xs, relu=True)
+    ys.backward(dfull[rank * per:(rank + 1) * per])
+    sl = slice(rank * per, (rank + 1) * per)
+    out["syncbn_path"] = pipc.small_all_reduce_path(None, dev)[1]["path"]
+    out["syncbn_fwd_err"] = float((ys.float() - yr[sl].float()).abs().max())
+    out["syncbn_dx_err"] = float((xs.grad.float() - xr.grad[sl].float()).abs().max() / xr.grad.float().abs().max())
+    out["syncbn_rm_err"] = float((bn_sync.running_mean - bn_ref.running_mean).abs().max())
+    out["syncbn_rv_err"] = float((bn_sync.running_var - bn_ref.running_var).abs().max())
+
+    # 5. a peer that never arrives: the kernel gives up after the limit, the flag is raised, the next call refuses
+    torch.cuda.synchronize()
+    tdist.barrier()
+    if rank == 0:
+        red.native.set_timeout(1.0)
+        red.all_reduce_(torch.ones(64, device=dev))
+        torch.cuda.synchronize()
+        out["timed_out"] = red.timed_out()
+        try:
+            red.all_reduce_(torch.ones(64, device=dev))
+            out["refused_after_timeout"] = False
+        except RuntimeError:
+            out["refused_after_timeout"] = True
+    tdist.barrier()
+    print(json.dumps(out), flush=True)
+    tdist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -288,6 +288,41 @@ def test_reducer_runs_the_rccl_path_with_a_size1_communicator(tmp_path):
     assert outs[1]["losses"][-1] < outs[1]["losses"][0]
 
 
+def test_ipc_small_allreduce_two_processes_on_one_gpu(tmp_path):
+    """SURVEY 5.8 layer 3 / 2.5 S4: the one-kernel all-reduce over IPC-mapped mailboxes, with two processes that
+    share GPU 0 (the only multi-process GPU set-up a one-GPU box allows; the peers' stores then stay on the device
+    instead of crossing xGMI, the protocol is the same).  Checks sums against a CPU all-reduce, bit-identical results
+    on both ranks, the path-selection self-check, replay inside a hipGraph, SyncBatchNorm through the IPC path
+    against plain BN over the concatenated batch, and the bounded wait when a peer never arrives."""
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29563", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "tests", "ipc_worker.py")], env=env,
+                                      cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=240)
+            assert p.returncode == 0, se[-3000:]
+            outs.append(json.loads(so.strip().splitlines()[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for o in outs:
+        assert o["setup_error"] is None, o
+        assert o["worst_rel_err"] < 1e-6 and o["same_bits"], o
+        assert o["validate_error"] is None, o
+        assert o["graph_vals"] == [o["graph_want"]] * 3, o
+        assert o["syncbn_path"] == "ipc", o
+        assert o["syncbn_fwd_err"] < 0.05 and o["syncbn_dx_err"] < 0.02, o
+        assert o["syncbn_rm_err"] < 1e-4 and o["syncbn_rv_err"] < 1e-3, o
+    r0 = [o for o in outs if o["rank"] == 0][0]
+    assert r0["timed_out"] and r0["refused_after_timeout"], r0
+    print("ipc all-reduce us/op:", r0["ipc_us"], " gloo-staged group us/op:", r0["group_us"])
+
+
 @pytest.mark.parametrize("opt", ["sgd", "adam"])
 def test_hip_graph_step_matches_eager(opt):
     """Engine(graph=True) captures forward+backward+optimizer after 3 eager steps; replays must produce the same
