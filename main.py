@@ -111,9 +111,15 @@ def main(argv=None) -> int:
         if args.resume:
             st = ckpt.load_checkpoint(args.resume, engine.net, engine.optimizer, sampler)
             start_epoch, global_step = st["epoch"], st["global_step"]
+        start_step = global_step
+        # per-bucket all-reduce timing for the JSON summary (needs the native RCCL communicator; timed events
+        # cannot be recorded while a hipGraph is captured)
+        comm_timing = bool(args.summary_json) and not args.graph and hasattr(engine.net.reducer, "set_timing") \
+            and engine.net.reducer.set_timing(True)
         print("Start")
         log.train_begin = time.time()
         done = False
+        sync_mark = None  # (global_step, wall time) right after a device sync, past the warm-up steps
         for e in range(start_epoch, epochs):
             sampler.set_epoch(e)
             for idx, (imgs, labels) in enumerate(train_loader):
@@ -129,6 +135,10 @@ def main(argv=None) -> int:
                     print("Epoch: {} step: {} loss: {}".format(e, idx, loss.item()))
                 prof.step()
                 timer.add(time.time() - start)
+                if sync_mark is None and args.summary_json and global_step - start_step >= 5:
+                    if torch.cuda.is_available():
+                        torch.cuda.synchronize()
+                    sync_mark = (global_step, time.time())
                 if args.checkpoint and args.checkpoint_every and global_step % args.checkpoint_every == 0:
                     ckpt.save_checkpoint(args.checkpoint, engine.net, engine.optimizer, e, global_step, sampler)
                 if args.steps is not None and global_step >= args.steps:
@@ -140,6 +150,7 @@ def main(argv=None) -> int:
                 break
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+        train_end = time.time()
         log.footer()
 
         if args.eval:
@@ -154,7 +165,18 @@ def main(argv=None) -> int:
         s.update({"world_size": world_size, "batch_size": batch_size, "model": args.model, "dataset": args.dataset,
                   "dtype": str(engine.dtype), "reducer": engine.net.reducer_kind,
                   "native_extension": pdt.native_available(),
-                  "library_fallbacks": dict(pF.fallback_counts)})
+                  "library_fallbacks": dict(pF.fallback_counts),
+                  "sync_bn_comm": engine.sync_bn_comm})
+        if sync_mark is not None and global_step > sync_mark[0]:
+            # device-synchronised on both ends, whole job: the BASELINE.md metric
+            s["images_per_sec_synchronised"] = (global_step - sync_mark[0]) * batch_size * world_size / (train_end - sync_mark[1])
+        if torch.cuda.is_available():
+            s["peak_hbm_bytes"] = int(torch.cuda.max_memory_allocated())
+        if comm_timing:
+            try:
+                s["comm"] = engine.net.reducer.comm_stats()  # of the last iteration
+            except RuntimeError as e:
+                s["comm"] = {"error": str(e)}
         metrics.write_json(args.summary_json, s)
     log.close()
     pdist.destroy_process_group()

@@ -99,7 +99,9 @@ PYBIND11_MODULE(_C, m) {
         .def("bucket_numels", &pdt::Reducer::bucket_numels)
         .def("bucket_tensors", &pdt::Reducer::bucket_tensors)
         .def("remove_hooks", &pdt::Reducer::remove_hooks)
-        .def("install_hooks", &pdt::Reducer::install_hooks);
+        .def("install_hooks", &pdt::Reducer::install_hooks)
+        .def("set_timing", &pdt::Reducer::set_timing)
+        .def("comm_stats", &pdt::Reducer::comm_stats, py::call_guard<py::gil_scoped_release>());
 
     m.def("plan_buckets", [](std::vector<int64_t> numels, std::vector<int64_t> order, int64_t elem, int64_t cap,
                              int64_t first_cap) {

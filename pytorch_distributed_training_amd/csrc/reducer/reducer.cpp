@@ -63,6 +63,7 @@ void Reducer::install_hooks() {
 Reducer::~Reducer() {
     remove_hooks();
     destroy_buckets();
+    if (bwd_end_) hipEventDestroy(bwd_end_);
 }
 
 void Reducer::remove_hooks() {
@@ -72,9 +73,13 @@ void Reducer::remove_hooks() {
 }
 
 void Reducer::destroy_buckets() {
-    for (auto& b : buckets_)
+    for (auto& b : buckets_) {
         if (b.done) hipEventDestroy(b.done);
+        if (b.t0) hipEventDestroy(b.t0);
+        if (b.t1) hipEventDestroy(b.t1);
+    }
     buckets_.clear();
+    timed_ = false;
 }
 
 void Reducer::build(const std::vector<int64_t>& order_in) {
@@ -177,7 +182,15 @@ void Reducer::launch(Bucket& b) {
         if (rccl_ && is_cuda_) {
             hipStream_t compute = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(b.flat.device().index()).stream();
             rccl_->fence_from(compute);           // comm stream waits for the flatten
+            if (timing_) {
+                if (!b.t0) {
+                    PDT_HIP(hipEventCreate(&b.t0));
+                    PDT_HIP(hipEventCreate(&b.t1));
+                }
+                PDT_HIP(hipEventRecord(b.t0, rccl_->stream()));
+            }
             rccl_->all_reduce_sum(b.flat);        // overlaps the rest of backward
+            if (timing_) PDT_HIP(hipEventRecord(b.t1, rccl_->stream()));
             PDT_HIP(hipEventRecord(b.done, rccl_->stream()));
         } else {
             std::vector<at::Tensor> ts{b.flat};
@@ -201,6 +214,11 @@ void Reducer::finalize() {
     if (rccl_ || pg_) {
         if (rccl_ && is_cuda_) {
             hipStream_t compute = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(params_[0].device().index()).stream();
+            if (timing_) {  // where backward's own work ends: what the buckets finish after this is exposed
+                if (!bwd_end_) PDT_HIP(hipEventCreate(&bwd_end_));
+                PDT_HIP(hipEventRecord(bwd_end_, compute));
+                timed_ = true;
+            }
             for (auto& b : buckets_) PDT_HIP(hipStreamWaitEvent(compute, b.done, 0));
         } else {
             for (auto& b : buckets_)
@@ -246,9 +264,43 @@ void Reducer::rebuild(const std::vector<int64_t>& order) {
                 }
             }
     }
-    for (auto& b : keep_alive)
+    for (auto& b : keep_alive) {
         if (b.done) hipEventDestroy(b.done);
+        if (b.t0) hipEventDestroy(b.t0);
+        if (b.t1) hipEventDestroy(b.t1);
+    }
     rebuilt_ = true;
+}
+
+void Reducer::set_timing(bool on) {
+    std::lock_guard<std::mutex> g(mu_);
+    TORCH_CHECK(!callback_queued_, "set_timing() must be called between iterations");
+    timing_ = on && is_cuda_ && rccl_ != nullptr;
+    timed_ = false;
+}
+
+std::tuple<std::vector<double>, double, double> Reducer::comm_stats() {
+    std::lock_guard<std::mutex> g(mu_);
+    TORCH_CHECK(timing_ && timed_, "comm_stats(): no timed iteration (set_timing(true), then run a backward; the "
+                                   "timing needs the native RCCL communicator)");
+    std::vector<double> per;
+    hipEvent_t first = nullptr, last = nullptr;
+    for (auto& b : buckets_) {
+        TORCH_CHECK(b.t0 && b.t1 && b.launched, "comm_stats(): a bucket was not reduced in the last iteration");
+        PDT_HIP(hipEventSynchronize(b.t1));
+        float ms = 0.f;
+        PDT_HIP(hipEventElapsedTime(&ms, b.t0, b.t1));
+        per.push_back(ms);
+        if (!first) first = b.t0;
+        last = b.t1;
+    }
+    PDT_HIP(hipEventSynchronize(bwd_end_));
+    float exposed = 0.f, span = 0.f;
+    PDT_HIP(hipEventElapsedTime(&span, first, last));
+    // negative when the last bucket finished before backward did: hipEventElapsedTime then reports an error or a
+    // negative number depending on the runtime, both mean "nothing exposed"
+    if (hipEventElapsedTime(&exposed, bwd_end_, last) != hipSuccess || exposed < 0.f) exposed = 0.f;
+    return {per, (double)exposed, (double)span};
 }
 
 std::vector<std::vector<int64_t>> Reducer::bucket_indices() const {

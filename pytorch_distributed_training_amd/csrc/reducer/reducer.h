@@ -21,6 +21,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../comm/rccl_comm.h"
@@ -50,6 +51,12 @@ class Reducer {
     // (re)create the AccumulateGrad nodes and their post hooks.  A node is bound to the stream that is current
     // when it is created, so before a hipGraph capture this is called under the capture stream.
     void install_hooks();
+    // Per-bucket all-reduce timing: two timed events per bucket on the communicator's stream and one
+    // on the compute stream where backward ends.  Off by default; not usable while a hipGraph is being captured.
+    void set_timing(bool on);
+    // (per-bucket all-reduce ms, ms the compute stream had to wait after backward, ms from the first all-reduce's
+    // start to the last one's end) of the most recent iteration; synchronises with the communicator's stream.
+    std::tuple<std::vector<double>, double, double> comm_stats();
 
    private:
     struct Bucket {
@@ -60,6 +67,7 @@ class Reducer {
         int64_t pending = 0;
         c10::intrusive_ptr<c10d::Work> work;
         hipEvent_t done = nullptr;
+        hipEvent_t t0 = nullptr, t1 = nullptr;  // timing mode only
         bool launched = false;
     };
     void build(const std::vector<int64_t>& order);
@@ -81,6 +89,8 @@ class Reducer {
     bool require_sync_ = true;
     bool rebuilt_ = false;
     bool callback_queued_ = false;
+    bool timing_ = false, timed_ = false;
+    hipEvent_t bwd_end_ = nullptr;
     int64_t iteration_ = 0;
     size_t next_bucket_ = 0;
     std::vector<int64_t> numels_, order_, ready_order_;

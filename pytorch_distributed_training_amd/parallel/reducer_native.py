@@ -140,3 +140,20 @@ class NativeReducer:
         """Recreate the AccumulateGrad nodes under the CURRENT stream (they remember the stream they were
         created on; a hipGraph capture must not pull the default stream in through them)."""
         self._r.install_hooks()
+
+    # -- per-bucket all-reduce timing (SURVEY 5.5) ------------------------------------------------------
+    def set_timing(self, on: bool) -> bool:
+        """Timed events around every bucket's all-reduce; True when the timing is available (native RCCL
+        communicator on a GPU).  Not to be left on while a hipGraph is captured."""
+        self._r.set_timing(bool(on))
+        return bool(on) and self.rccl is not None
+
+    def comm_stats(self) -> dict:
+        """Of the most recent iteration: per-bucket all-reduce time, how long the compute stream had to wait
+        for the buckets after backward's own work ended, and the overlap fraction = 1 - exposed / total."""
+        per, exposed, span = self._r.comm_stats()
+        total = float(sum(per))
+        sizes = [int(t.numel() * t.element_size()) for t in self._r.bucket_tensors()]
+        return {"bucket_bytes": sizes, "bucket_allreduce_ms": [float(v) for v in per], "allreduce_ms_total": total,
+                "allreduce_span_ms": float(span), "exposed_ms": float(exposed),
+                "overlap_fraction": (1.0 - min(exposed, total) / total) if total > 0 else 1.0}

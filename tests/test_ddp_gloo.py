@@ -184,6 +184,7 @@ def test_main_py_two_ranks_gloo(tmp_path, free_port, repo_root):
 
     s = json.load(open(tmp_path / "s.json"))
     assert s["world_size"] == 2 and s["steps"] == 10
+    assert s["images_per_sec_synchronised"] > 0 and "comm" not in s  # (bucket timing needs the RCCL communicator)
     # resume for a second epoch
     r2 = subprocess.run(cmd[:-2] + ["--resume", "ck.pt", "--epochs", "2"], cwd=tmp_path, capture_output=True,
                         text=True, timeout=300)

@@ -273,7 +273,14 @@ def test_reducer_runs_the_rccl_path_with_a_size1_communicator(tmp_path):
         "g = torch.Generator().manual_seed(0)\n"
         "x = torch.rand(32, 3, 64, 64, generator=g).cuda(); y = torch.randint(0, 10, (32,), generator=g).cuda()\n"
         "losses = [float(eng.train_step(x, y)) for _ in range(6)]\n"
-        "print(json.dumps({'losses': losses, 'rccl': eng.net.reducer.rccl is not None, 'kind': eng.net.reducer_kind}))\n"
+        "stats = None\n"
+        "if eng.net.reducer.set_timing(True):\n"
+        "    losses.append(float(eng.train_step(x, y)))\n"
+        "    stats = eng.net.reducer.comm_stats()\n"
+        "    eng.net.reducer.set_timing(False)\n"
+        "else:\n"
+        "    losses.append(float(eng.train_step(x, y)))\n"
+        "print(json.dumps({'losses': losses, 'rccl': eng.net.reducer.rccl is not None, 'kind': eng.net.reducer_kind, 'comm': stats}))\n"
     ) % ROOT
     outs = []
     for force in ("0", "1"):
@@ -286,6 +293,11 @@ def test_reducer_runs_the_rccl_path_with_a_size1_communicator(tmp_path):
     assert not outs[0]["rccl"] and outs[1]["rccl"]
     assert outs[0]["losses"] == outs[1]["losses"], outs
     assert outs[1]["losses"][-1] < outs[1]["losses"][0]
+    # per-bucket all-reduce timing (the JSON summary's "comm" block): only with the communicator
+    c = outs[1]["comm"]
+    assert outs[0]["comm"] is None and c is not None
+    assert len(c["bucket_allreduce_ms"]) == len(c["bucket_bytes"]) >= 2 and all(v >= 0 for v in c["bucket_allreduce_ms"])
+    assert 0.0 <= c["overlap_fraction"] <= 1.0 and c["allreduce_span_ms"] >= 0 and c["exposed_ms"] >= 0
 
 
 def test_ipc_small_allreduce_two_processes_on_one_gpu(tmp_path):
@@ -373,6 +385,7 @@ def test_main_py_single_gpu_through_launcher(tmp_path):
     assert list((tmp_path / "log_Job0").glob("*.pt.trace.json")), "profiler trace missing"
     s = json.load(open(tmp_path / "s.json"))
     assert s["reducer"] == "native" and s["native_extension"] and s["dtype"] == "torch.bfloat16"
+    assert s["peak_hbm_bytes"] > 0 and s["images_per_sec_synchronised"] > 0
     from pytorch_distributed_training_amd.models import resnet50
 
     ck = torch.load(tmp_path / "ck.pt", weights_only=True)
