@@ -24,6 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 LINK_GBPS = 153.0          # xGMI per-link bandwidth (task brief; calibrate with a 2-GPU copy)
 COLL_LATENCY_US = 25.0     # launch + sync latency per RCCL collective (10-30 us)
+IPC_SMALL_US = 12.0        # one IpcAllReduce kernel (measured launch-to-launch with 2 processes on one MI355X;
+                           # across xGMI add the store round trip, a few us): the SyncBN statistics path
 GRAD_BYTES = 25_557_032 * 4
 
 
@@ -40,7 +42,8 @@ def run_measured(n: int, args) -> dict:
     return json.loads(line)
 
 
-def model_curve(step_ms_1gpu: float, batch: int, sync_bn: bool, bucket_mb: float = 16.0, algo: str = "ring"):
+def model_curve(step_ms_1gpu: float, batch: int, sync_bn: bool, bucket_mb: float = 16.0, algo: str = "ring",
+                syncbn_comm: str = "ipc"):
     """Predicted whole-job images/sec for N in {1,2,4,8}."""
     rows = []
     for n in (1, 2, 4, 8):
@@ -55,7 +58,8 @@ def model_curve(step_ms_1gpu: float, batch: int, sync_bn: bool, bucket_mb: float
             comm_ms = bw_ms + n_buckets * COLL_LATENCY_US * 1e-3
             backward_ms = step_ms_1gpu * 0.6  # what the all-reduce can hide under
             exposed = max(0.0, comm_ms - backward_ms) + bw_ms / n_buckets + COLL_LATENCY_US * 1e-3  # tail bucket
-            syncbn = 2 * 53 * COLL_LATENCY_US * 1e-3 if sync_bn else 0.0
+            per_msg_us = IPC_SMALL_US if syncbn_comm == "ipc" else COLL_LATENCY_US
+            syncbn = 2 * 53 * per_msg_us * 1e-3 if sync_bn else 0.0
             t = step_ms_1gpu + exposed + syncbn
         rows.append({"n_gpus": n, "ms_per_step": round(t, 3), "images_per_sec": round(n * batch / t * 1e3, 1),
                      "efficiency": round(step_ms_1gpu / t, 4), "kind": "measured" if n == 1 else "modelled"})
@@ -69,6 +73,8 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch_size", type=int, default=256)
     ap.add_argument("--sync_bn", action="store_true")
+    ap.add_argument("--syncbn_comm", default="ipc", choices=["ipc", "rccl"],
+                    help="modelled path of the SyncBN statistics all-reduce (parallel/ipc.py)")
     ap.add_argument("--model-from", dest="model_from", default=None, help="bench.py JSON line/log of a 1-GPU run")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
@@ -78,8 +84,8 @@ def main() -> int:
         assert d["n_gpus"] == 1
         batch = d["config"]["per_gpu_batch"]
         result = {"source": a.model_from, "link_GBps": LINK_GBPS, "collective_latency_us": COLL_LATENCY_US,
-                  "ring": model_curve(d["ms_per_step"], batch, a.sync_bn, algo="ring"),
-                  "direct": model_curve(d["ms_per_step"], batch, a.sync_bn, algo="direct")}
+                  "ring": model_curve(d["ms_per_step"], batch, a.sync_bn, algo="ring", syncbn_comm=a.syncbn_comm),
+                  "direct": model_curve(d["ms_per_step"], batch, a.sync_bn, algo="direct", syncbn_comm=a.syncbn_comm)}
     else:
         import torch
 
