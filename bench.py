@@ -51,6 +51,8 @@ def main(argv=None) -> int:
     ap.add_argument("--sync_bn", action="store_true")
     ap.add_argument("--bucket_cap_mb", type=lambda v: v if v == "auto" else float(v), default=None)
     ap.add_argument("--backend", default=None)
+    ap.add_argument("--device", default=None, choices=["auto", "cuda", "cpu"],
+                    help="with --backend gloo: cuda keeps the tensors on the GPU (several ranks may share one)")
     ap.add_argument("--reducer", default=None)
     ap.add_argument("--graph", action="store_true", help="capture the steady-state step in one hipGraph")
     args = ap.parse_args(argv)
@@ -64,7 +66,8 @@ def main(argv=None) -> int:
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus and world_env > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
-    env = pdist.init_process_group(backend=args.backend, local_rank=int(os.environ.get("LOCAL_RANK", "0")))
+    env = pdist.init_process_group(backend=args.backend, local_rank=int(os.environ.get("LOCAL_RANK", "0")),
+                                   device=args.device)
     on_gpu = env.device.type == "cuda"
     if on_gpu and not native_available():
         raise SystemExit("the native extension is not built: run `python __graft_entry__.py build`")

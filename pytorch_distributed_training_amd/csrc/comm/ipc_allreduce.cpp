@@ -2,6 +2,7 @@
 
 #include <c10/util/Exception.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -88,6 +89,8 @@ void IpcAllReduce::all_reduce(float* data, int64_t n, hipStream_t s) {
     TORCH_CHECK(ready_, "IpcAllReduce: open_peers() has not run");
     TORCH_CHECK(n >= 0 && n <= mb_.cap, "IpcAllReduce: ", n, " elements exceed the mailbox capacity ", mb_.cap);
     TORCH_CHECK(!timed_out(), "IpcAllReduce: an earlier all-reduce ran out of time waiting for a peer");
+    static const bool debug = std::getenv("PDT_IPC_DEBUG") != nullptr;
+    if (debug) fprintf(stderr, "[ipc rank %d] call %ld n=%ld stream=%p\n", mb_.rank, (long)++calls_, (long)n, (void*)s);
     launch_ipc_allreduce(data, (int)n, mb_, s);
 }
 

@@ -63,6 +63,7 @@ class IpcAllReduce {
     int device_;
     size_t bytes_ = 0;
     bool ready_ = false;
+    long calls_ = 0;
     IpcMailboxes mb_{};
     volatile uint32_t* host_status_ = nullptr;
     hipIpcMemHandle_t handle_{};

@@ -55,6 +55,7 @@ def init_process_group(
     init_method: str = "env://",
     local_rank: int | None = None,
     timeout_s: float | None = None,
+    device: str | None = None,
 ) -> DistEnv:
     """Initialise the default group; process group first, then device selection
     (the order of ``main.py:34-35``)."""
@@ -85,10 +86,20 @@ def init_process_group(
     if not tdist.is_initialized():
         tdist.init_process_group(backend=torch_backend, init_method=init_method, **kwargs)
 
-    if torch.cuda.is_available() and torch_backend == "nccl":
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+    # ``device="cuda"`` (or PDT_DEVICE=cuda) with the gloo backend keeps the tensors on the GPU and moves the
+    # collectives through the host: a way to rehearse W > 1 on a box with ONE GPU (RCCL refuses two ranks on
+    # one device).  Diagnostic only: see bench/micro/engine_w2_worker.py for what was observed.
+    want = (device or os.environ.get("PDT_DEVICE", "auto")).lower()
+    if want not in ("auto", "cuda", "cpu"):
+        raise ValueError(f"unknown device {want!r}; choose auto, cuda or cpu")
+    if torch.cuda.is_available() and (torch_backend == "nccl" or want == "cuda"):
+        # (ranks may share a device only in the gloo rehearsal mode)
+        local_dev = local_rank if torch_backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_dev)
+        device = torch.device("cuda", local_dev)
     else:
+        if want == "cuda":
+            raise RuntimeError("device cuda requested but no GPU is visible")
         device = torch.device("cpu")
     _ENV = DistEnv(
         rank=tdist.get_rank(),

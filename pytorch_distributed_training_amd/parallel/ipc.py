@@ -172,6 +172,15 @@ def _decide(group, device):
     if mode in ("torch", "rccl", "group", "nccl") or device.type != "cuda":
         info["why"] = "selected" if device.type == "cuda" else "cpu tensors"
         return None, info
+    if mode == "auto" and tdist.get_backend(group) != "nccl":
+        # GPU tensors under a gloo group (the one-GPU rehearsal of W > 1).  gloo moves a GPU tensor through the
+        # host and makes the compute stream wait for the copy back from one of ITS threads, in the middle of
+        # backward; together with kernels that wait for a peer on the same stream that closes a cycle
+        # (observed: two ranks sharing a GPU stop in the first backward).  RCCL keeps every dependency on the
+        # device and the reducer lets the compute stream wait for it only after backward, so the IPC path is
+        # for RCCL jobs; PDT_SYNCBN_COMM=ipc still forces it.
+        info["why"] = "the group is not an RCCL group"
+        return None, info
     ipc = IpcSmallAllReduce(group, device)
     if not ipc.ok:
         info["why"] = ipc.error

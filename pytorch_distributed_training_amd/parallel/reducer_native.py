@@ -56,6 +56,8 @@ def _rccl_or_none(process_group, world: int, device):
         return None
     if world == 1:
         return make_rccl_comm(process_group, high_priority=True)  # None unless PDT_FORCE_COMM=1
+    if tdist.get_backend(process_group) != "nccl":
+        return None  # GPU tensors under a gloo group (one-GPU rehearsal of W > 1): ranks may share a device
     comm, err = None, None
     try:
         comm = make_rccl_comm(process_group, high_priority=True)
