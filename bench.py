@@ -50,6 +50,7 @@ def main(argv=None) -> int:
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam", "adamw"])
     ap.add_argument("--sync_bn", action="store_true")
     ap.add_argument("--bucket_cap_mb", type=lambda v: v if v == "auto" else float(v), default=None)
+    ap.add_argument("--grad_dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient buckets")
     ap.add_argument("--backend", default=None)
     ap.add_argument("--device", default=None, choices=["auto", "cuda", "cpu"],
                     help="with --backend gloo: cuda keeps the tensors on the GPU (several ranks may share one)")
@@ -75,7 +76,7 @@ def main(argv=None) -> int:
     engine = Engine(EngineConfig(
         model=args.model, num_classes=args.num_classes, dtype=args.dtype, optimizer=args.optimizer,
         lr=0.1 if args.optimizer == "sgd" else 1e-3, momentum=0.9, weight_decay=1e-4 if args.optimizer == "sgd" else 0.0,
-        sync_bn=args.sync_bn, bucket_cap_mb=args.bucket_cap_mb, reducer=args.reducer, seed=0, graph=args.graph,
+        sync_bn=args.sync_bn, bucket_cap_mb=args.bucket_cap_mb, grad_dtype=args.grad_dtype, reducer=args.reducer, seed=0, graph=args.graph,
         image_size=args.image_size))
     batch_model = None
     if args.batch_size <= 0:
@@ -138,7 +139,7 @@ def main(argv=None) -> int:
                 "backend": env.backend, "baseline_images_per_sec": round(base, 1),
                 "library_fallbacks": dict(pF.fallback_counts), "final_loss": final_loss,
                 "hip_graph": bool(engine._graph is not None), "batch_model": batch_model, "bucket_autotune": engine.net.bucket_autotune,
-                "sync_bn_comm": engine.sync_bn_comm,
+                "sync_bn_comm": engine.sync_bn_comm, "grad_dtype": args.grad_dtype,
             },
         }
         print(json.dumps(out), flush=True)

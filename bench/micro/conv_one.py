@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--time", action="store_true", help="print us per call of fwd / dgrad / wgrad (event-timed)")
     ap.add_argument("--shapes", nargs="+", default=["64,56,64,3,1", "256,14,256,3,1", "64,56,256,1,1", "256,56,64,1,1"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -33,6 +34,19 @@ def main():
             native.conv2d_dgrad(dy, w, tuple(x.shape), s, pad)
             native.conv2d_wgrad(dy, x, tuple(w.shape), s, pad)
         torch.cuda.synchronize()
+        if a.time:
+            res = []
+            for fn in (lambda: native.conv2d_fwd(x, w, s, pad, True), lambda: native.conv2d_dgrad(dy, w, tuple(x.shape), s, pad),
+                       lambda: native.conv2d_wgrad(dy, x, tuple(w.shape), s, pad)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                fn()
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                res.append(e0.elapsed_time(e1) * 100.0)
+            print(f"time {spec} cfg={os.environ.get('PDT_IGEMM_CFG', '0')} fwd {res[0]:.1f} dgrad {res[1]:.1f} wgrad {res[2]:.1f} us", flush=True)
         print("done", spec, flush=True)
 
 

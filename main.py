@@ -61,6 +61,8 @@ def get_parser() -> argparse.ArgumentParser:
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="GPU compute dtype")
     p.add_argument("--sync_bn", dest="sync_bn", action="store_true", default=True)
     p.add_argument("--no_sync_bn", dest="sync_bn", action="store_false")
+    p.add_argument("--grad_dtype", default="fp32", choices=["fp32", "bf16"],
+                   help="dtype of the gradient buckets: bf16 halves the bytes the all-reduce moves (.grad stays fp32)")
     p.add_argument("--bucket_cap_mb", default=None, type=lambda v: v if v == "auto" else float(v),
                    help="gradient bucket size in MiB, or 'auto' to time all-reduces on this job's links and pick one")
     p.add_argument("--backend", default=None, choices=["rccl", "nccl", "gloo"])
@@ -102,7 +104,7 @@ def main(argv=None) -> int:
         engine = Engine(EngineConfig(
             model=args.model, num_classes=args.num_classes, dtype=args.dtype, optimizer=args.optimizer, lr=args.lr,
             momentum=args.momentum, weight_decay=args.weight_decay, sync_bn=args.sync_bn,
-            bucket_cap_mb=args.bucket_cap_mb, seed=args.seed, graph=args.graph,
+            bucket_cap_mb=args.bucket_cap_mb, grad_dtype=args.grad_dtype, seed=args.seed, graph=args.graph,
             # the torch profiler's one cycle (wait 2 + warmup 2 + active 6) ends at step 10: capture after it, so
             # that the trace shows real kernels and no collection is active while the stream is being captured
             graph_warmup=12 if args.profile == "torch" else 3,

@@ -229,6 +229,7 @@ void Reducer::finalize() {
         }
     }
     for (auto& b : buckets_) {
+        std::vector<at::Tensor> srcs, dsts;  // unflatten (N3): bucket -> .grad in one multi-tensor launch (+ cast)
         for (size_t j = 0; j < b.plan.params.size(); ++j) {
             at::Tensor& p = params_[b.plan.params[j]];
             at::Tensor& v = b.views[j];
@@ -237,9 +238,20 @@ void Reducer::finalize() {
                 if (!cur.defined() || cur.data_ptr() != v.data_ptr()) p.mutable_grad() = v;
             } else {
                 if (!p.grad().defined()) p.mutable_grad() = at::empty_like(p);
-                p.mutable_grad().copy_(v);
+                at::Tensor& g = p.mutable_grad();
+                const auto gt = g.scalar_type(), vt = v.scalar_type();
+                if (is_cuda_ && g.is_non_overlapping_and_dense() && g.strides() == v.strides() &&
+                    reinterpret_cast<uintptr_t>(g.data_ptr()) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(v.data_ptr()) % 16 == 0 && (gt == at::kFloat || gt == at::kBFloat16) &&
+                    (vt == at::kFloat || vt == at::kBFloat16) && (dsts.empty() || dsts[0].scalar_type() == gt)) {
+                    srcs.push_back(v);
+                    dsts.push_back(g);
+                } else {
+                    g.copy_(v);
+                }
             }
         }
+        if (!srcs.empty()) multi_flatten_tensors(srcs, dsts, 1.0);
     }
     ++iteration_;
 }

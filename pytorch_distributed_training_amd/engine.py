@@ -36,6 +36,7 @@ class EngineConfig:
     weight_decay: float = 0.0
     sync_bn: bool = True
     bucket_cap_mb: float | None = None
+    grad_dtype: str = "fp32"  # dtype of the gradient buckets (what the all-reduce moves): fp32, or bf16 = half the bytes
     broadcast_buffers: bool | str = "auto"
     reducer: str | None = None
     seed: int | None = None
@@ -82,6 +83,7 @@ class Engine:
         self.net = DistributedDataParallel(
             net, device_ids=dev_ids, output_device=dev_ids[0] if dev_ids else None,
             bucket_cap_mb=cfg.bucket_cap_mb, broadcast_buffers=cfg.broadcast_buffers,
+            grad_dtype={"fp32": None, "bf16": torch.bfloat16}[cfg.grad_dtype],
             compute_dtype=self.dtype, reducer=cfg.reducer)
         self.net.train()
         self._graph = None          # (CUDAGraph, static_imgs, static_labels, static_loss)

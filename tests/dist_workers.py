@@ -66,7 +66,8 @@ def _data(n=8, seed=123):
     return torch.randn(n, 3, 8, 8, generator=g), torch.randint(0, 5, (n,), generator=g)
 
 
-def ddp_grads(rank, world, reducer="py", sync_bn=True, bucket_cap_mb=None, steps=1, no_sync_first=False):
+def ddp_grads(rank, world, reducer="py", sync_bn=True, bucket_cap_mb=None, steps=1, no_sync_first=False,
+              grad_dtype=None):
     """Gradients of DDP(+SyncBN) over a sharded batch == gradients of one process over the full batch."""
     from pytorch_distributed_training_amd import nn as pnn
     from pytorch_distributed_training_amd.parallel import DistributedDataParallel
@@ -74,7 +75,8 @@ def ddp_grads(rank, world, reducer="py", sync_bn=True, bucket_cap_mb=None, steps
     net = _toy(seed=rank)  # different init per rank: the ctor broadcast must fix that
     if sync_bn:
         net = pnn.convert_sync_batchnorm(net)
-    ddp = DistributedDataParallel(net, reducer=reducer, bucket_cap_mb=bucket_cap_mb, first_bucket_mb=bucket_cap_mb)
+    ddp = DistributedDataParallel(net, reducer=reducer, bucket_cap_mb=bucket_cap_mb, first_bucket_mb=bucket_cap_mb,
+                                  grad_dtype=getattr(torch, grad_dtype) if grad_dtype else None)
     x, y = _data()
     per = x.shape[0] // world
     xs, ys = x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
@@ -98,6 +100,7 @@ def ddp_grads(rank, world, reducer="py", sync_bn=True, bucket_cap_mb=None, steps
         "buckets": [list(b.param_indices) for b in ddp.reducer.bucket_specs()],
         "rebuilt": bool(ddp.reducer.rebuilt),
         "kind": ddp.reducer_kind,
+        "bucket_dtype": str(_bucket_tensors(ddp)[0].dtype),
         "grad_is_view": all(p.grad.untyped_storage().data_ptr() in
                             {t.untyped_storage().data_ptr() for t in _bucket_tensors(ddp)} for p in ddp.parameters()),
     })

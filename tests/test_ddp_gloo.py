@@ -83,6 +83,21 @@ def test_ddp_syncbn_grads_equal_full_batch(reducer, world, free_port, tmp_path):
 
 
 @pytest.mark.parametrize("reducer", REDUCERS)
+def test_bf16_gradient_buckets(reducer, free_port, tmp_path):
+    """``grad_dtype=torch.bfloat16``: the buckets (what crosses the links) are bf16, ``.grad`` stays fp32 and equal on
+    every rank; the values match the full-batch gradients to bf16 precision."""
+    res = spawn("ddp_grads", 2, free_port, tmp_path, reducer=reducer, sync_bn=True, bucket_cap_mb=0.0005, steps=2,
+                grad_dtype="bfloat16")
+    oracle, _ = full_batch_oracle()
+    assert res[0]["bucket_dtype"] == "torch.bfloat16" and not res[0]["grad_is_view"]
+    for n, p in oracle.named_parameters():
+        g0, g1 = res[0]["grads"][n], res[1]["grads"][n]
+        assert g0.dtype == torch.float32 and torch.equal(g0, g1), n
+        scale = float(p.grad.abs().max()) + 1e-12
+        assert float((g0 - p.grad).abs().max()) / scale < 2e-2, n
+
+
+@pytest.mark.parametrize("reducer", REDUCERS)
 def test_bucket_rebuild_after_first_iteration(reducer, free_port, tmp_path):
     res = spawn("ddp_grads", 2, free_port, tmp_path, reducer=reducer, sync_bn=True, bucket_cap_mb=0.0005, steps=3)
     oracle, _ = full_batch_oracle()

@@ -335,6 +335,24 @@ def test_ipc_small_allreduce_two_processes_on_one_gpu(tmp_path):
     print("ipc all-reduce us/op:", r0["ipc_us"], " gloo-staged group us/op:", r0["group_us"])
 
 
+def test_bf16_gradient_buckets_follow_the_fp32_run():
+    """``grad_dtype="bf16"``: gradients are cast into bf16 buckets by the multi-tensor flatten kernel and cast back
+    into the fp32 ``.grad`` by ONE unflatten launch per bucket; training follows the fp32-bucket run to bf16
+    precision and the buckets really are bf16."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(32, 3, 64, 64, generator=g).cuda()
+    y = torch.randint(0, 10, (32,), generator=g).cuda()
+    runs = {}
+    for gd in ("fp32", "bf16"):
+        eng = _engine(model="resnet18", num_classes=10, optimizer="sgd", lr=0.05, sync_bn=False, grad_dtype=gd)
+        runs[gd] = [float(eng.train_step(x, y)) for _ in range(6)]
+        dt = {t.dtype for t in eng.net.reducer.bucket_tensors()}
+        assert dt == ({torch.bfloat16} if gd == "bf16" else {torch.float32})
+        assert all(p.grad.dtype == torch.float32 for p in eng.net.parameters())
+    assert runs["bf16"] == pytest.approx(runs["fp32"], rel=0.05, abs=0.02), runs
+    assert runs["bf16"][-1] < 0.5 * runs["bf16"][0]
+
+
 @pytest.mark.parametrize("opt", ["sgd", "adam"])
 def test_hip_graph_step_matches_eager(opt):
     """Engine(graph=True) captures forward+backward+optimizer after 3 eager steps; replays must produce the same
