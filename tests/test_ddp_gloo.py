@@ -201,10 +201,13 @@ def test_main_py_two_ranks_gloo(tmp_path, free_port, repo_root):
     assert s["world_size"] == 2 and s["steps"] == 10
     assert s["images_per_sec_synchronised"] > 0 and "comm" not in s  # (bucket timing needs the RCCL communicator)
     # resume for a second epoch
-    r2 = subprocess.run(cmd[:-2] + ["--resume", "ck.pt", "--epochs", "2"], cwd=tmp_path, capture_output=True,
+    r2 = subprocess.run(cmd[:-2] + ["--resume", "ck.pt", "--epochs", "2", "--eval"], cwd=tmp_path, capture_output=True,
                         text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr[-3000:]
     assert "Epoch: 1 step: 0" in r2.stdout and "Epoch: 0 step: 0" not in r2.stdout
+    # the reference's commented-out evaluation loop (main.py:119-130), sharded over the ranks, printed by rank 0
+    acc = [l for l in r2.stdout.splitlines() if l.startswith("eval accuracy:")]
+    assert len(acc) == 1 and 0.0 <= float(acc[0].split(":")[1]) <= 1.0
 
 
 def test_bucket_cap_autotune_agrees_across_ranks(free_port, tmp_path):
