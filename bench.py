@@ -94,7 +94,11 @@ def main(argv=None) -> int:
             torch.cuda.synchronize()
 
     loss = None
-    for _ in range(args.warmup):
+    # The first iterations are not steady state whatever the caller's --warmup is: lazy code-object loading,
+    # allocator growth, and the reducer's bucket rebuild at the start of iteration 2.  With fewer than 3 warm-up
+    # steps requested, the missing ones run here, untimed and reported as config.priming_steps.
+    priming = max(0, 3 - args.warmup)
+    for _ in range(priming + args.warmup):
         loss = engine.train_step(*next(it))
     sync()
     t0 = time.perf_counter()
@@ -139,7 +143,7 @@ def main(argv=None) -> int:
                 "backend": env.backend, "baseline_images_per_sec": round(base, 1),
                 "library_fallbacks": dict(pF.fallback_counts), "final_loss": final_loss,
                 "hip_graph": bool(engine._graph is not None), "batch_model": batch_model, "bucket_autotune": engine.net.bucket_autotune,
-                "sync_bn_comm": engine.sync_bn_comm, "grad_dtype": args.grad_dtype,
+                "priming_steps": priming, "sync_bn_comm": engine.sync_bn_comm, "grad_dtype": args.grad_dtype,
             },
         }
         print(json.dumps(out), flush=True)

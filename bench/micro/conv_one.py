@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--no_stats", action="store_true", help="forward without the fused BN-statistics epilogue")
     ap.add_argument("--time", action="store_true", help="print us per call of fwd / dgrad / wgrad (event-timed)")
     ap.add_argument("--shapes", nargs="+", default=["64,56,64,3,1", "256,14,256,3,1", "64,56,256,1,1", "256,56,64,1,1"])
     a = ap.parse_args()
@@ -36,7 +37,7 @@ def main():
         torch.cuda.synchronize()
         if a.time:
             res = []
-            for fn in (lambda: native.conv2d_fwd(x, w, s, pad, True), lambda: native.conv2d_dgrad(dy, w, tuple(x.shape), s, pad),
+            for fn in (lambda: native.conv2d_fwd(x, w, s, pad, not a.no_stats), lambda: native.conv2d_dgrad(dy, w, tuple(x.shape), s, pad),
                        lambda: native.conv2d_wgrad(dy, x, tuple(w.shape), s, pad)):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 fn()
