@@ -48,7 +48,7 @@ class IpcSmallAllReduce:
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.capacity = capacity
         if timeout_s is None:
-            timeout_s = float(os.environ.get("PDT_IPC_TIMEOUT_S", "30"))
+            timeout_s = float(os.environ.get("PDT_IPC_TIMEOUT_S", "120"))
         self.timeout_s = timeout_s
         self.native = None
         err = None
