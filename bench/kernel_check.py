@@ -354,6 +354,23 @@ def check_layernorm(M, D, time_it):
     run_case(f"layernorm {tag}", run)
 
 
+def check_colsum(M, N, time_it):
+    tag = f"M{M} N{N}"
+    x = (torch.randn(M, N, device=DEV) + 0.25).to(torch.bfloat16)
+
+    def run():
+        got = native.colsum(x)
+        want = x.double().sum(0).float()
+        e = float((got - want).abs().max() / want.abs().max().clamp_min(1e-6))
+        extra = None
+        if time_it:
+            us = timeit(lambda: native.colsum(x))
+            us_t = timeit(lambda: x.sum(0, dtype=torch.float32))
+            extra = {"us": round(us, 1), "GBps": round(2 * x.numel() / us / 1e3, 1), "aten_us": round(us_t, 1)}
+        record(f"colsum {tag}", got.dtype == torch.float32 and e < 1e-4, e, extra)
+    run_case(f"colsum {tag}", run)
+
+
 # ----------------------------------------------------------------------------- others
 def check_pool():
     for (B, C, H, W) in ((2, 64, 16, 16), (3, 64, 15, 17), (4, 64, 112, 112), (9, 64, 112, 112)):  # last: > 512 blocks (XCD grouping)
@@ -497,6 +514,9 @@ def main():
     if only is None or "ln" in only:
         for shp in ((5, 768), (197 * 3 + 1, 256), (1030, 1024)) + (() if a.quick else ((128 * 197, 768),)):
             check_layernorm(*shp, a.time)
+    if only is None or "ln" in only or "colsum" in only:
+        for shp in ((1, 8), (37, 72), (1000, 768), (513, 1000)) + (() if a.quick else ((128 * 197, 768), (128 * 197, 2304), (128 * 197, 3072))):
+            check_colsum(*shp, a.time)
     if only is None or "stem" in only:
         for shp in ((2, 32, 32), (3, 64, 48)) + (() if a.quick else ((128, 224, 224),)):
             check_stem(*shp, a.time)

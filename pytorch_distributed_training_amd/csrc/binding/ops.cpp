@@ -904,6 +904,21 @@ void multi_flatten_tensors(std::vector<at::Tensor>& srcs, std::vector<at::Tensor
     multi_flatten(srcs, dsts, scale);
 }
 
+// fp32 column sums of a row-major bf16 matrix [M, N] (Linear bias gradients): one streaming pass + slab reduce
+Tensor colsum(const Tensor& x) {
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kBFloat16 && x.dim() == 2 && x.is_contiguous(),
+                "colsum: expected a contiguous 2-D bf16 GPU tensor");
+    const long M = x.size(0), N = x.size(1);
+    TORCH_CHECK(N % 8 == 0 && N < (1L << 24) && reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0,
+                "colsum: columns must be a multiple of 8 and the data 16-B aligned");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    if (M == 0) return at::zeros({N}, x.options().dtype(at::kFloat));
+    constexpr int kMaxChunks = 256;
+    Tensor slab = at::empty({kMaxChunks, N}, x.options().dtype(at::kFloat));
+    const int chunks = launch_colsum_bf16(x.data_ptr(), M, (int)N, slab.data_ptr<float>(), kMaxChunks, cur_stream(x));
+    return reduce_slab(slab, chunks, N);
+}
+
 void bind_ops(pybind11::module& m) {
     m.def("conv2d_fwd", &conv2d_fwd);
     m.def("conv2d_dgrad", &conv2d_dgrad, pybind11::arg("dy"), pybind11::arg("wt"), pybind11::arg("x_shape"), pybind11::arg("kh"),
@@ -917,6 +932,7 @@ void bind_ops(pybind11::module& m) {
     m.def("conv_stem_wgrad", &conv_stem_wgrad);
     m.def("transpose_weight", &transpose_weight);
     m.def("transpose_weights", &transpose_weights, pybind11::arg("weights"), pybind11::arg("outs") = pybind11::none());
+    m.def("colsum", &colsum);
     m.def("bn_stats", &bn_stats);
     m.def("bn_finalize", &bn_finalize);
     m.def("bn_sum_partials", &bn_sum_partials);

@@ -323,6 +323,51 @@ __global__ __launch_bounds__(256) void k_reduce_slab(const float* __restrict__ s
     }
 }
 
+
+// Column sums of a row-major bf16 matrix [M][N] (bias gradients of the Linear layers: dy summed over tokens) into
+// fp32 partial rows slab[chunk][N].  A block owns 128 columns x one row chunk: 16 lanes x 16 B cover the 256
+// contiguous bytes of a row, 16 row lanes walk the chunk with four independent loads in flight each.
+__global__ __launch_bounds__(256) void k_colsum_bf16(const bf16* __restrict__ x, long M, int N, int rows_per_block,
+                                                     float* __restrict__ slab) {
+    __shared__ float red[16][128 + 4];
+    const int tid = threadIdx.x, cx = tid & 15, ry = tid >> 4;
+    const int col = blockIdx.x * 128 + cx * 8;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    if (col < N) {
+        const bf16* base = x + col;
+        long r = r0 + ry;
+        for (; r + 48 < r1; r += 64) {
+            bf16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(base + (r + 16 * u) * N);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] += (float)v[u][k];
+        }
+        for (; r < r1; r += 16) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + r * N);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += (float)v[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[ry][cx * 8 + k] = a[k];
+    __syncthreads();
+    if (tid < 128) {
+        const int c = blockIdx.x * 128 + tid;
+        if (c < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += red[q][tid];
+            slab[(long)blockIdx.y * N + c] = s;
+        }
+    }
+}
 }  // namespace
 
 void launch_multi_flatten(const int64_t* table, int ntensors, int nchunks, float scale, int src_dtype,
@@ -424,6 +469,19 @@ int launch_reduce_rows_l1(const float* slab, int nparts, long stride, int n, flo
     const int chunks = (nparts + ppc - 1) / ppc;
     hipLaunchKernelGGL(k_reduce_slab, dim3(colblocks, chunks), dim3(256), 0, s, slab, nparts, stride, n, ppc, out);
     return chunks;
+}
+
+int launch_colsum_bf16(const void* x, long M, int N, float* slab, int max_chunks, hipStream_t s) {
+    const int colblocks = (N + 127) / 128;
+    long chunks = (M + 63) / 64;  // at least 64 rows per block
+    const long want = (2048 + colblocks - 1) / colblocks;
+    if (chunks > want) chunks = want;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    const int rpb = (int)((M + chunks - 1) / chunks);
+    chunks = (M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(k_colsum_bf16, dim3(colblocks, (unsigned)chunks), dim3(256), 0, s, (const bf16*)x, M, N, rpb, slab);
+    return (int)chunks;
 }
 
 }  // namespace pdt

@@ -54,6 +54,9 @@ void launch_multi_transpose(const TransposeArgs& a, hipStream_t s);
 constexpr int kReduceChunks = 32;
 void launch_reduce_slab(const float* slab, int nparts, long stride, int n, float* out, float* tmp, hipStream_t s);
 // first level only: out[max_chunks][n] gets <= max_chunks partial rows; returns the row count
+// column sums of a row-major bf16 [M][N] matrix (N % 8 == 0) into fp32 partial rows slab[<= max_chunks][N];
+// returns the number of rows written
+int launch_colsum_bf16(const void* x, long M, int N, float* slab, int max_chunks, hipStream_t s);
 int launch_reduce_rows_l1(const float* slab, int nparts, long stride, int n, float* out, int max_chunks,
                           hipStream_t s);
 

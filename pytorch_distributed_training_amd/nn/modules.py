@@ -17,6 +17,7 @@ import torch.nn as tnn
 import torch.nn.functional as tF
 
 from . import functional as F
+from ..ops import backend_for
 
 
 class Conv2d(tnn.Conv2d):
@@ -72,7 +73,7 @@ class _LowpLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = (dy2.t() @ x2).to(ctx.wdt)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0, dtype=torch.float32).to(ctx.wdt)  # fp32 accumulation without a separate cast pass
+            db = backend_for(dy2).colsum(dy2).to(ctx.wdt)  # fp32 accumulation in one streaming pass
         return dx, dw, db, None
 
 

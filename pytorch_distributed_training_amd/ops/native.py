@@ -256,6 +256,15 @@ def global_avgpool_bwd(dy, x_shape):
 
 
 # --------------------------------------------------------------------- loss
+def colsum(x):
+    """fp32 column sums of a 2-D tensor (Linear bias gradient): the HIP streaming kernel for contiguous bf16 rows
+    of a multiple of 8 columns, ``sum(0)`` with fp32 accumulation otherwise."""
+    if (x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous() and x.shape[1] % 8 == 0
+            and x.data_ptr() % 16 == 0):
+        return _C.colsum(x)
+    return x.sum(0, dtype=torch.float32)
+
+
 def softmax_ce_fwd_bwd(logits, labels):
     if logits.dtype not in (_BF16, torch.float32):
         return reference.softmax_ce_fwd_bwd(logits, labels)

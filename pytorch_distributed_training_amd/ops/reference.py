@@ -223,6 +223,10 @@ def global_avgpool_bwd(dy, x_shape):
 
 
 # ----------------------------------------------------------------- loss ----
+def colsum(x):
+    return x.sum(0, dtype=torch.float32)
+
+
 def softmax_ce_fwd_bwd(logits, labels):
     """Mean CE loss (fp32 scalar) and ``dlogits = (softmax - onehot)/B`` in the
     logits dtype, in one pass."""

@@ -75,6 +75,14 @@ def test_layernorm_kernels(kc, shape):
     _assert_all_ok(kc, n)
 
 
+@pytest.mark.parametrize("shape", [(1, 8), (37, 72), (1000, 768), (513, 1000), (8 * 197, 3072)])
+def test_colsum_kernel(kc, shape):
+    """bias-gradient column sums (bf16 rows -> fp32) against a float64 sum"""
+    n = len(kc.RESULTS)
+    kc.check_colsum(*shape, False)
+    _assert_all_ok(kc, n)
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 32), (3, 64, 48), (4, 224, 224)])
 def test_stem_conv_native_fwd_wgrad(kc, shape):
     n = len(kc.RESULTS)
