@@ -412,6 +412,9 @@ def test_main_py_single_gpu_through_launcher(tmp_path):
     s = json.load(open(tmp_path / "s.json"))
     assert s["reducer"] == "native" and s["native_extension"] and s["dtype"] == "torch.bfloat16"
     assert s["peak_hbm_bytes"] > 0 and s["images_per_sec_synchronised"] > 0
+    # --graph auto: a single-process run on 32x32 images is launch-bound, the steady-state step is replayed from a
+    # hipGraph captured after the profiler's cycle
+    assert s["hip_graph"] and s["hip_graph_failed"] is None, s
     from pytorch_distributed_training_amd.models import resnet50
 
     ck = torch.load(tmp_path / "ck.pt", weights_only=True)
