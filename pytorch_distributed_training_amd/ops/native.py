@@ -300,30 +300,38 @@ def nchw_to_nhwc_lowp(x, dtype=_BF16, scale: float = 1.0):
 
 
 # --------------------------------------------------------------- optimizers
+_REFUSALS = ("wrong device/dtype", "must be dense", "16-B aligned", "layout != param layout", "multi-tensor ops take")
+
+
+def _layout_refusal(e: Exception) -> bool:
+    msg = str(e)
+    return any(r in msg for r in _REFUSALS)
+
+
 def multi_adam(params, grads, ms, vs, lps, lr, beta1, beta2, eps, weight_decay, step, adamw, grad_scale=1.0,
                step_dev=None):
     """``step_dev`` (fp32 device scalar holding the step count): the bias corrections are computed in the kernel
     from it, so a captured graph replays correctly; ``step`` is then only used by the fallback path."""
-    ok = all(_aligned(t) for t in (*params, *grads, *ms, *vs)) and all(lp is None or _aligned(lp) for lp in lps) \
-        and all(p.dtype == torch.float32 for p in params) and len({g.dtype for g in grads}) == 1
-    if not ok:
+    # the extension validates every tensor (device, dtype, dense, 16-B aligned, layouts equal) before it launches
+    # anything; a refusal sends the whole group through the per-tensor oracle path
+    try:
+        _C.multi_adam(list(params), list(grads), list(ms), list(vs), list(lps), lr, beta1, beta2, eps, weight_decay,
+                      int(step), bool(adamw), grad_scale, step_dev)
+    except RuntimeError as e:
+        if not _layout_refusal(e):
+            raise
         for p, g, m, v, lp in zip(params, grads, ms, vs, lps):
             reference.adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, float(step), adamw, grad_scale, lp)
-        bump_weights_epoch()
-        return
-    _C.multi_adam(list(params), list(grads), list(ms), list(vs), list(lps), lr, beta1, beta2, eps, weight_decay,
-                  int(step), bool(adamw), grad_scale, step_dev)
     bump_weights_epoch()
 
 
 def multi_sgd(params, grads, bufs, lps, lr, momentum, dampening, weight_decay, nesterov, first, grad_scale=1.0):
-    ok = all(_aligned(t) for t in (*params, *grads, *bufs)) and all(lp is None or _aligned(lp) for lp in lps) \
-        and all(p.dtype == torch.float32 for p in params) and len({g.dtype for g in grads}) == 1
-    if not ok:
+    try:
+        _C.multi_sgd(list(params), list(grads), list(bufs), list(lps), lr, momentum, dampening, weight_decay,
+                     bool(nesterov), bool(first), grad_scale)
+    except RuntimeError as e:
+        if not _layout_refusal(e):
+            raise
         for p, g, b, lp in zip(params, grads, bufs, lps):
             reference.sgd_step(p, g, b, lr, momentum, dampening, weight_decay, nesterov, first, grad_scale, lp)
-        bump_weights_epoch()
-        return
-    _C.multi_sgd(list(params), list(grads), list(bufs), list(lps), lr, momentum, dampening, weight_decay,
-                 bool(nesterov), bool(first), grad_scale)
     bump_weights_epoch()

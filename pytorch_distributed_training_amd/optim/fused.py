@@ -97,6 +97,7 @@ class _FusedBase(Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self.__dict__["_state_loaded"] = True
         self.__dict__.pop("_fused_steps", None)  # re-derived from the loaded per-parameter steps
         for gi, t in self.__dict__.get("_step_dev", {}).items():
             params = [p for p in self.param_groups[gi]["params"] if p in self.state]
@@ -110,7 +111,10 @@ class _FusedBase(Optimizer):
         self.__dict__["_capturable"] = bool(on)
 
     def _move_loaded_state(self, params):
-        # after load_state_dict the state tensors may sit on another device / layout
+        # after load_state_dict the state tensors may sit on another device / layout (checked once per load)
+        if not self.__dict__.get("_state_loaded", False):
+            return
+        self.__dict__["_state_loaded"] = False
         for p in params:
             st = self.state[p]
             for k in self._state_keys:
