@@ -421,6 +421,19 @@ def test_main_py_single_gpu_through_launcher(tmp_path):
     resnet50().load_state_dict(ck["model"], strict=True)
 
 
+def test_resnet152_bf16_step_many_buckets():
+    """BASELINE.json config 4: the deep model (465 parameter tensors, 60 M parameters) steps through the native
+    path and its gradients spread over many 16 MiB buckets."""
+    eng = _engine(model="resnet152", optimizer="sgd", lr=0.02, sync_bn=False)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(16, 3, 64, 64, generator=g).cuda()
+    y = torch.randint(0, 1000, (16,), generator=g).cuda()
+    losses = [float(eng.train_step(x, y)) for _ in range(5)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    assert sum(p.numel() for p in eng.net.parameters()) == 60192808
+    assert len(eng.net.reducer.bucket_tensors()) >= 12
+
+
 def test_vit_b16_bf16_step():
     eng = _engine(model="vit_b_16", optimizer="adamw", lr=1e-3, sync_bn=False)
     g = torch.Generator().manual_seed(0)
