@@ -11,6 +11,7 @@ cast + NCHW->NHWC fused in one kernel, SyncBN on its own communicator.
 """
 from __future__ import annotations
 
+import sys
 from dataclasses import dataclass
 
 import torch
@@ -133,7 +134,7 @@ class Engine:
                 self._graph = None
                 torch.cuda.synchronize(self.device)
                 if self.rank == 0:
-                    print(f"[pdt] hipGraph capture failed, continuing eagerly: {self._graph_failed}", flush=True)
+                    print(f"[pdt] hipGraph capture failed, continuing eagerly: {self._graph_failed}", file=sys.stderr, flush=True)
         return self._eager_step(imgs, labels)
 
     def _capture(self, imgs, labels, key) -> None:

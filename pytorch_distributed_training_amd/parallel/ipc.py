@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import os
 import socket
+import sys
 import time
 
 import torch
@@ -204,7 +205,7 @@ def small_all_reduce_path(group, device):
         _paths[key] = _decide(group, device)
         if tdist.get_rank(group) == 0 and os.environ.get("PDT_QUIET", "0") == "0":
             _, info = _paths[key]
-            print(f"[syncbn-comm] {info}", flush=True)
+            print(f"[syncbn-comm] {info}", file=sys.stderr, flush=True)
     return _paths[key]
 
 

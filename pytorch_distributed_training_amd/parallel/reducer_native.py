@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import itertools
 import os
+import sys
 
 import torch
 import torch.distributed as tdist
@@ -69,7 +70,7 @@ def _rccl_or_none(process_group, world: int, device):
         return comm
     if tdist.get_rank(process_group) == 0 or err is not None:
         print(f"[pdt] native RCCL communicator unavailable ({err!r}); all-reducing through torch.distributed",
-              flush=True)
+              file=sys.stderr, flush=True)
     _shared_comm.pop((id(process_group), True), None)
     return None
 
