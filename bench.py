@@ -59,6 +59,11 @@ def main(argv=None) -> int:
     ap.add_argument("--reducer", default=None)
     ap.add_argument("--graph", action="store_true", help="capture the steady-state step in one hipGraph")
     args = ap.parse_args(argv)
+    # stdout carries exactly ONE line, the JSON result: everything else this process or its libraries print
+    # (RCCL's version banner, c10d notices) goes to stderr for the duration of the run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     from pytorch_distributed_training_amd import dist as pdist
     from pytorch_distributed_training_amd import native_available
@@ -148,7 +153,8 @@ def main(argv=None) -> int:
                 "priming_steps": priming, "sync_bn_comm": engine.sync_bn_comm, "grad_dtype": args.grad_dtype,
             },
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     sync()
     if env.world_size > 1 and on_gpu:
         # every rank is past the last collective: leave without running communicator destructors, so a rank
