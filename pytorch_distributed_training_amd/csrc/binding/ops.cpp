@@ -919,7 +919,96 @@ Tensor colsum(const Tensor& x) {
     return reduce_slab(slab, chunks, N);
 }
 
+// ------------------------------------------------------------------------------------- gemm
+void check_mat_bf16(const Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kBFloat16 && t.dim() == 2, name, ": expected a 2-D bf16 GPU tensor");
+    TORCH_CHECK(t.stride(1) == 1 && t.stride(0) >= t.size(1) && t.stride(0) % 8 == 0 && t.size(1) % 8 == 0, name,
+                ": rows must be contiguous, with length and pitch multiples of 8 elements");
+    TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, ": data pointer must be 16-B aligned");
+    TORCH_CHECK(t.stride(0) < (1L << 22), name, ": row pitch too large");
+}
+
+// c = epilogue(a @ b^T): a [M,K], b [N,K] bf16 (K contiguous).  bias fp32 [N] (added before rounding);
+// act 1 = GELU (erf); residual [M,N] bf16 added last; gelu_in [M,N]: result multiplied by GELU'(gelu_in);
+// want_preact: also return the value before the activation; want_colsum: fp32 column sums of the result.
+std::tuple<Tensor, Tensor, Tensor> gemm_nt(const Tensor& a, const Tensor& b, const c10::optional<Tensor>& bias,
+                                           const c10::optional<Tensor>& residual, const c10::optional<Tensor>& gelu_in,
+                                           int64_t act, bool want_preact, bool want_colsum) {
+    check_mat_bf16(a, "a");
+    check_mat_bf16(b, "b");
+    const long M = a.size(0), K = a.size(1), N = b.size(0);
+    TORCH_CHECK(b.size(1) == K, "gemm_nt: a is [", M, ",", K, "], b is [", N, ",", b.size(1), "]");
+    TORCH_CHECK(N % 8 == 0 && N < (1L << 24) && K < (1L << 24), "gemm_nt: N must be a multiple of 8");
+    TORCH_CHECK(act == 0 || act == 1, "gemm_nt: act is 0 (none) or 1 (GELU)");
+    TORCH_CHECK(!want_preact || act == 1, "gemm_nt: want_preact needs an activation");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(a.device());
+    Tensor c = at::empty({M, N}, a.options());
+    Tensor preact, colsum_out;
+    GemmArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.A = a.data_ptr(); g.B = b.data_ptr(); g.C = c.data_ptr();
+    g.M = M; g.N = (int)N; g.K = (int)K;
+    g.lda = (int)a.stride(0); g.ldb = (int)b.stride(0); g.ldc = (int)N;
+    g.act = (int)act;
+    if (bias.has_value() && bias->defined()) {
+        check_vec_f32(*bias, N, "bias");
+        g.bias = bias->data_ptr<float>();
+    }
+    if (residual.has_value() && residual->defined()) {
+        check_mat_bf16(*residual, "residual");
+        TORCH_CHECK(residual->size(0) == M && residual->size(1) == N, "residual must be [M,N]");
+        g.residual = residual->data_ptr();
+        g.ldr = (int)residual->stride(0);
+    }
+    if (gelu_in.has_value() && gelu_in->defined()) {
+        check_mat_bf16(*gelu_in, "gelu_in");
+        TORCH_CHECK(gelu_in->size(0) == M && gelu_in->size(1) == N, "gelu_in must be [M,N]");
+        g.gelu_in = gelu_in->data_ptr();
+        g.ldu = (int)gelu_in->stride(0);
+    }
+    if (want_preact) {
+        preact = at::empty({M, N}, a.options());
+        g.preact_out = preact.data_ptr();
+    }
+    Tensor slab;
+    const int m_tiles = gemm_m_tiles(M);
+    if (want_colsum) {
+        slab = at::empty({std::max(m_tiles, 1), N}, a.options().dtype(at::kFloat));
+        g.colsum_slab = slab.data_ptr<float>();
+    }
+    if (M > 0) launch_gemm_nt(g, cur_stream(a));
+    if (want_colsum) {
+        if (M == 0) colsum_out = at::zeros({N}, a.options().dtype(at::kFloat));
+        else colsum_out = m_tiles == 1 ? slab.view({N}) : reduce_slab(slab, m_tiles, N);
+    }
+    return {c, preact, colsum_out};
+}
+
+// dW [N,K] fp32 = dy[M,N]^T @ x[M,K]: the weight-gradient kernel of a 1x1 convolution over M "pixels"
+// (transposing LDS reads, deterministic split-K slab)
+Tensor linear_wgrad(const Tensor& dy, const Tensor& x) {
+    check_mat_bf16(dy, "dy");
+    check_mat_bf16(x, "x");
+    TORCH_CHECK(dy.is_contiguous() && x.is_contiguous(), "linear_wgrad: contiguous operands expected");
+    const long M = x.size(0), K = x.size(1), N = dy.size(1);
+    TORCH_CHECK(dy.size(0) == M, "linear_wgrad: row count mismatch");
+    TORCH_CHECK(M < (1L << 31) && M * K * 2 < (1L << 32) && M * N * 2 < (1L << 32), "linear_wgrad: operand too large");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    if (M == 0) return at::zeros({N, K}, x.options().dtype(at::kFloat));
+    WgradGeom g{(int)M, 1, 1, (int)K, 1, 1, (int)N, 1, 1, 1, 0, 1};
+    g.splits = conv_wgrad_splits(g);
+    const long wsize = N * K;
+    Tensor slab = at::empty({g.splits, wsize}, x.options().dtype(at::kFloat));
+    launch_conv_wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr<float>(), g, cur_stream(x));
+    Tensor flat = g.splits == 1 ? slab.view({wsize}) : reduce_slab(slab, g.splits, wsize);
+    return flat.view({N, K});
+}
+
 void bind_ops(pybind11::module& m) {
+    m.def("gemm_nt", &gemm_nt, pybind11::arg("a"), pybind11::arg("b"), pybind11::arg("bias") = pybind11::none(),
+          pybind11::arg("residual") = pybind11::none(), pybind11::arg("gelu_in") = pybind11::none(),
+          pybind11::arg("act") = 0, pybind11::arg("want_preact") = false, pybind11::arg("want_colsum") = false);
+    m.def("linear_wgrad", &linear_wgrad);
     m.def("conv2d_fwd", &conv2d_fwd);
     m.def("conv2d_dgrad", &conv2d_dgrad, pybind11::arg("dy"), pybind11::arg("wt"), pybind11::arg("x_shape"), pybind11::arg("kh"),
           pybind11::arg("kw"), pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("addend") = pybind11::none(),

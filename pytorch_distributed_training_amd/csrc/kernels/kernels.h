@@ -197,6 +197,27 @@ bool wgrad_win_plan(WinGeom& g);  // false: shape not supported by the window ke
 // slab: fp32 [splits][N][KH*KW][C] (mode 0) or [splits][64][7][7][3] (mode 1)
 void launch_wgrad_win(const void* dy, const void* x, float* slab, const WinGeom& g, hipStream_t s);
 
+// ---- bf16 GEMM C = epilogue(A . B^T) on MFMA (gemm.hip): Linear fwd / dgrad, 1x1 convolutions -----------
+struct GemmArgs {
+    const void* A;       // [M][lda] bf16, K contiguous
+    const void* B;       // [N][ldb] bf16, K contiguous
+    void* C;             // [M][ldc] bf16
+    long M;
+    int N, K;            // N % 8 == 0, K % 8 == 0
+    int lda, ldb, ldc;   // elements, multiples of 8
+    const float* bias;   // [N] fp32 or null: added in fp32 before the rounding to bf16
+    const void* residual;  // [M][ldr] bf16 or null: added in the store pass (after the activation)
+    int ldr;
+    const void* gelu_in;   // [M][ldu] bf16 or null: the stored value is multiplied by GELU'(gelu_in)
+    int ldu;
+    void* preact_out;      // [M][ldc] bf16 or null: the value before the activation is written here too
+    int act;               // 0 none, 1 GELU (erf form)
+    float* colsum_slab;    // [m_tiles][N] fp32 or null: per-m-tile column sums of the stored values
+    int m_tiles, n_tiles;  // filled by the launcher
+};
+int gemm_m_tiles(long M);
+void launch_gemm_nt(const GemmArgs& a, hipStream_t s);
+
 // ---- 3-channel stem (conv_stem.hip) -----------------------------------------------------------
 // x NHWC bf16 [B,H,W,3] -> xp [B][H+6][W+8][4] (image at row +3 / col +4, zeros elsewhere, channel 3 = 0)
 void launch_stem_pack_x(const void* x, void* xp, int B, int H, int W, hipStream_t s);
