@@ -41,8 +41,12 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;       // 16 KiB: 128 rows of 128 B
 constexpr int STAGE_BYTES = 4 * HALF_BYTES;    // A-lo, A-hi, B-lo, B-hi
-constexpr int OPITCH = BN * 2 + 16;            // staged output row pitch (bytes)
-constexpr int LDS_BYTES = BM * OPITCH;         // 135168 >= 2 * STAGE_BYTES
+// LDS map (all 160 KiB of the CU): [stage 0: 64 KiB][extra: 32 KiB][stage 1: 64 KiB].  The epilogue stages half
+// an output tile (128 rows) in "extra" plus the stage buffer that does NOT receive the next tile's first K-tile.
+constexpr int EXTRA_OFF = STAGE_BYTES, STAGE1_OFF = STAGE_BYTES + 32768;
+constexpr int LDS_BYTES = STAGE1_OFF + STAGE_BYTES;  // 163840
+constexpr int OPITCH = BN * 2 + 16;                  // staged output row pitch (bytes)
+static_assert(128 * OPITCH <= STAGE_BYTES + 32768, "half-tile staging fits");
 
 __device__ __forceinline__ float gelu_erf_part(float u, float* pdf_out) {
     // 0.5 * (1 + erf(u / sqrt(2))) by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7), and exp(-u^2/2) / sqrt(2 pi)
@@ -64,66 +68,80 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
     return cdf + u * pdf;
 }
 
-// byte offset of 16-B chunk `chunk` of row `row` inside a half-tile of 128-B rows
-__device__ __forceinline__ int half_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int stage_off(int s) { return s ? STAGE1_OFF : 0; }
 
+// Persistent: gridDim.x workgroups (one per CU) walk the tile list.  Blocks b and b+8 share an XCD; every XCD label
+// gets a contiguous range of tiles so that the workgroups that run together on one L2 share operand panels.
+// EXTRA: 0 none, 1 residual added, 2 multiplied by GELU'(gelu_in).  ACT: GELU, the pre-activation is written too.
+// Compile-time so that the K loop does not carry a dozen wave-uniform conditions in scalar registers.
+template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    // XCD-aware, bijective block -> tile map (blocks b and b+8 share an XCD): contiguous tile ranges per XCD
     const int total = a.m_tiles * a.n_tiles;
-    int tile;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
-        const int q = total >> 3, r = total & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int tile_n = tile % a.n_tiles, tile_m = tile / a.n_tiles;
-    const long m0 = (long)tile_m * BM;
-    const int n0 = tile_n * BN;
-    const int rows_m = (int)((a.M - m0) < BM ? (a.M - m0) : BM);   // valid rows of this tile
-    const int rows_n = (a.N - n0) < BN ? (a.N - n0) : BN;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tq = total >> 3, trem = total & 7;
+    const int range_start = xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq;
+    const int range_count = tq + (xcd < trem ? 1 : 0);
+    const int wg_per_xcd = ((int)gridDim.x - xcd + 7) >> 3;
+    int ti = slot;
+    if (ti >= range_count) return;
 
-    // descriptors re-based at the tile's first row: offsets inside stay far below 2^31
-    const char* Abase = static_cast<const char*>(a.A) + m0 * a.lda * 2;
-    const char* Bbase = static_cast<const char*>(a.B) + (long)n0 * a.ldb * 2;
-    const i32x4 ra = make_rsrc_words(Abase, (uint32_t)((long)rows_m * a.lda * 2));
-    const i32x4 rb = make_rsrc_words(Bbase, (uint32_t)((long)rows_n * a.ldb * 2));
-
-    // ---- DMA source offsets: in every phase each thread issues 2 pieces (j = 0, 1) of one half-tile.
-    // piece pc = wave * 2 + j covers rows pc*8 .. pc*8+7 (1 KiB); lane -> row pc*8 + lane/8, physical chunk lane%8,
-    // which holds logical chunk (lane%8) ^ ((row >> 1) & 7).
+    // ---- per-tile operand state (A/B side), recomputed for the NEXT tile while the current one is being stored
+    i32x4 ra, rb;
     uint32_t voffA[2][2], voffB[2][2];
+    long m0;
+    int n0, rows_m, tile_m;
     int lch[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int pc = wave * 2 + j;
-        const int row = pc * 8 + (lane >> 3);
+        const int row = (wave * 2 + j) * 8 + (lane >> 3);
         lch[j] = (lane & 7) ^ ((row >> 1) & 7);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r = h * 128 + row;
-            voffA[h][j] = r < rows_m ? (uint32_t)r * (uint32_t)(a.lda * 2) + (uint32_t)(lch[j] * 16) : kOOB;
-            voffB[h][j] = r < rows_n ? (uint32_t)r * (uint32_t)(a.ldb * 2) + (uint32_t)(lch[j] * 16) : kOOB;
-        }
     }
-    const uint32_t lds0 = lds_address(smem);
-    const uint32_t piece_base = lds0 + (uint32_t)wave * 2048u;  // + j * 1024
+    auto setup = [&](int idx) {
+        // grouped order: bands of a.group_m tile rows, m fastest inside a band (group_m = 1: n fastest)
+        const int band_tiles = a.group_m * a.n_tiles;
+        const int band = idx / band_tiles, rem = idx - band * band_tiles;
+        int band_rows = a.m_tiles - band * a.group_m;
+        band_rows = band_rows < a.group_m ? band_rows : a.group_m;
+        const int tn = rem / band_rows;
+        tile_m = band * a.group_m + (rem - tn * band_rows);
+        m0 = (long)tile_m * BM;
+        n0 = tn * BN;
+        rows_m = (int)((a.M - m0) < BM ? (a.M - m0) : BM);
+        const int rows_n = (a.N - n0) < BN ? (a.N - n0) : BN;
+        // descriptors re-based at the tile's first row: offsets inside stay far below 2^31
+        ra = make_rsrc_words(static_cast<const char*>(a.A) + m0 * a.lda * 2, (uint32_t)((long)rows_m * a.lda * 2));
+        rb = make_rsrc_words(static_cast<const char*>(a.B) + (long)n0 * a.ldb * 2, (uint32_t)((long)rows_n * a.ldb * 2));
+        // DMA source offsets: in every phase each thread issues 2 pieces (j = 0, 1) of one half-tile.  Piece
+        // pc = wave * 2 + j covers rows pc*8 .. pc*8+7 (1 KiB); lane -> row pc*8 + lane/8, physical chunk lane%8,
+        // which holds logical chunk (lane%8) ^ ((row >> 1) & 7).
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 8 + (lane >> 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = h * 128 + row;
+                voffA[h][j] = r < rows_m ? (uint32_t)r * (uint32_t)(a.lda * 2) + (uint32_t)(lch[j] * 16) : kOOB;
+                voffB[h][j] = r < rows_n ? (uint32_t)r * (uint32_t)(a.ldb * 2) + (uint32_t)(lch[j] * 16) : kOOB;
+            }
+        }
+    };
+    const uint32_t piece_base = lds_address(smem) + (uint32_t)wave * 2048u;  // + j * 1024
 
     const int nt = (a.K + BK - 1) / BK;
-    const bool ragged_k = (a.K % BK) != 0;
-    // slot: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
-    auto issue = [&](int slot, int t) {
-        const uint32_t dst = piece_base + (uint32_t)((t & 1) * STAGE_BYTES + slot * HALF_BYTES);
+    // slot: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi; t = K-tile of the current operand state; par = its stage buffer
+    auto issue = [&](int hslot, int t, int par) {
+        const uint32_t dst = piece_base + (uint32_t)(stage_off(par) + hslot * HALF_BYTES);
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(t * BK * 2);
-        const bool isB = slot >= 2;
-        const int h = slot & 1;
+        const bool isB = hslot >= 2;
+        const int h = hslot & 1;
         uint32_t v0 = isB ? voffB[h][0] : voffA[h][0];
         uint32_t v1 = isB ? voffB[h][1] : voffA[h][1];
-        if (ragged_k && t == nt - 1) {  // chunks past the end of the reduction axis read zeros
+        if (RAGGED && t == nt - 1) {  // chunks past the end of the reduction axis read zeros
             if (t * BK + lch[0] * 8 >= a.K) v0 = kOOB;
             if (t * BK + lch[1] * 8 >= a.K) v1 = kOOB;
         }
@@ -145,148 +163,198 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
         a_off[ks] = wr * HALF_BYTES + lo;
         b_off[ks] = 2 * HALF_BYTES + (wc >> 1) * HALF_BYTES + (wc & 1) * 64 * 128 + lo;
     }
+    const int och = tid & 31, orow = tid >> 5;  // store pass: 32 chunks of 8 columns per row, 16 rows per pass
 
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // ---- prologue: all of tile 0, and B-lo of tile 1
-    issue(0, 0);
-    issue(1, 0);
-    issue(2, 0);
-    issue(3, 0);
-    if (nt > 1) {
-        issue(2, 1);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // ---- prologue of the first tile: K-tile 0
+    int gk = 0;  // K-tiles consumed so far: K-tile t of the current tile lives in stage (gk + t) & 1
+    setup(range_start + ti);
+    issue(0, 0, 0);
+    issue(1, 0, 0);
+    issue(2, 0, 0);
+    issue(3, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one phase behind their SIMD partners
 
-    bf16x8 bfrag[2][4];
-    for (int t = 0; t < nt; ++t) {
-        const char* st = smem + (t & 1) * STAGE_BYTES;
-        const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+    while (true) {
+        f32x4_t acc[8][4];
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            const int mh = ph >> 1, ks = ph & 1;
-            // ---------------- load segment (the partner wave is in its MFMA segment)
-            bf16x8 afrag[4];
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                afrag[i] = *reinterpret_cast<const bf16x8*>(st + a_off[ks] + (mh * 64 + i * 16) * 128);
-            if (mh == 0) {
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one phase behind their SIMD partners
+        bf16x8 bfrag[2][4];
+        for (int t = 0; t < nt; ++t) {
+            const int par = (gk + t) & 1;
+            const char* st = smem + stage_off(par);
+            const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    bfrag[ks][j] = *reinterpret_cast<const bf16x8*>(st + b_off[ks] + j * 16 * 128);
-            }
-            if (ph == 0) {
-                if (more1) issue(3, t + 1);
-            } else if (ph == 1) {
-                if (more1) issue(0, t + 1);
-            } else if (ph == 2) {
-                if (more1) issue(1, t + 1);
-            } else {
-                if (more2) {
-                    issue(2, t + 2);
-                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // everything of tile t+1 has landed
+            for (int ph = 0; ph < 4; ++ph) {
+                const int mh = ph >> 1, ks = ph & 1;
+                // ---------------- load segment (the partner wave is in its MFMA segment)
+                bf16x8 afrag[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    afrag[i] = *reinterpret_cast<const bf16x8*>(st + a_off[ks] + (mh * 64 + i * 16) * 128);
+                if (mh == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        bfrag[ks][j] = *reinterpret_cast<const bf16x8*>(st + b_off[ks] + j * 16 * 128);
+                }
+                if (ph == 0) {
+                    if (more1) {
+                        if (t == 0) issue(2, 1, par ^ 1);  // (later tiles: issued two K-tiles ahead, below)
+                        issue(3, t + 1, par ^ 1);
+                    }
+                } else if (ph == 1) {
+                    if (more1) issue(0, t + 1, par ^ 1);
+                } else if (ph == 2) {
+                    if (more1) issue(1, t + 1, par ^ 1);
                 } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (more2) {
+                        issue(2, t + 2, par);
+                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // everything of K-tile t+1 has landed
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
+                __builtin_amdgcn_s_barrier();
+                // ---------------- MFMA segment
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[ks][j], afrag[i],
+                                                                                      acc[mh * 4 + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups: every fragment read is done
+        gk += nt;
+
+        // -------------------------------------------------------------------------------- epilogue
+        const long om0 = m0;
+        const int on0 = n0, orows_m = rows_m, otile_m = tile_m;
+        ti += wg_per_xcd;
+        const bool has_next = ti < range_count;
+        const int npar = gk & 1;  // stage that receives the next tile's first K-tile
+        if (has_next) {
+            setup(range_start + ti);
+            issue(0, 0, npar);
+            issue(1, 0, npar);
+            issue(2, 0, npar);
+            issue(3, 0, npar);
+        }
+        char* Os = smem + (npar == 0 ? EXTRA_OFF : 0);
+        const int ncol = on0 + och * 8;
+        const bool col_ok = ncol < a.N;  // N % 8 == 0
+        const uint32_t cbytes = (uint32_t)((long)orows_m * a.ldc * 2);
+        const __amdgpu_buffer_rsrc_t rc = make_rsrc(static_cast<char*>(a.C) + om0 * a.ldc * 2, cbytes);
+        const __amdgpu_buffer_rsrc_t rp = make_rsrc(ACT ? static_cast<char*>(a.preact_out) + om0 * a.ldc * 2 : nullptr, ACT ? cbytes : 0u);
+        // one optional extra operand: the residual (added) or the GELU input (its derivative multiplies)
+        const void* extra = EXTRA == 1 ? a.residual : a.gelu_in;
+        const int lde = EXTRA == 1 ? a.ldr : a.ldu;
+        const __amdgpu_buffer_rsrc_t re = make_rsrc(EXTRA ? static_cast<const char*>(extra) + om0 * lde * 2 : nullptr,
+                                                    EXTRA ? (uint32_t)((long)orows_m * lde * 2) : 0u);
+        float csum[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) csum[k] = 0.f;
+
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            if (wr == hh) {
+                // lane holds, for 16x16 tile (i, j): row i*16 + lane%16, columns j*16 + (lane/16)*4 + 0..3
+                const int wcol = wc * 64 + lq * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    const int n = on0 + wcol + j * 16;
+                    if (a.bias != nullptr && n < a.N) bv = *reinterpret_cast<const f32x4_t*>(a.bias + n);  // N % 4 == 0
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const f32x4_t v = acc[i][j] + bv;
+                        const bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(Os + (i * 16 + l15) * OPITCH + (wcol + j * 16) * 2) = pk;
+                    }
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            // ---------------- MFMA segment
-            __builtin_amdgcn_s_setprio(1);
+            // coalesced pass over 128 rows: 8 passes of 16 rows, 16 B per lane.  Everything read from global memory is
+            // fetched for all passes first; every thread issues the same number of stores (masked ones are dropped by
+            // the descriptor's range check), so a counted wait can tell the next tile's DMA from the stores behind it.
+            bf16x8 ev[8];
+            uint32_t coff[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int p = 0; p < 8; ++p) {
+                const int row = hh * 128 + p * 16 + orow;
+                coff[p] = col_ok ? (uint32_t)row * (uint32_t)(a.ldc * 2) + (uint32_t)(ncol * 2) : kOOB;
+            }
+            if (EXTRA != 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[mh * 4 + i][j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[ks][j], afrag[i], acc[mh * 4 + i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+                for (int p = 0; p < 8; ++p) {
+                    const int row = hh * 128 + p * 16 + orow;
+                    ev[p] = buffer_load_bf16x8(re, col_ok ? (uint32_t)row * (uint32_t)(lde * 2) + (uint32_t)(ncol * 2) : kOOB);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int lrow = p * 16 + orow;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + lrow * OPITCH + och * 16);
+                if (ACT)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, coff[p], 0, 0);
+                if (ACT) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (bf16)gelu_f((float)v[k]);
+                }
+                if (EXTRA == 2) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] * gelu_grad_f((float)ev[p][k]));
+                }
+                if (EXTRA == 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)ev[p][k]);
+                }
+                if (COLSUM && hh * 128 + lrow < orows_m) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) csum[k] += (float)v[k];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, coff[p], 0, 0);
+            }
+            if (hh == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();  // the staged rows are read before the other half overwrites them
+            }
+        }
+        // the next tile's first K-tile (issued before the 16 / 32 stores of this thread) has landed
+        if (ACT) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (COLSUM) {
+            // per-tile column sums of what was stored (bias gradient of the layer that produced this gradient):
+            // threads och + 32 * r own the same 8 columns: lanes l and l^32 in a wave, then the 8 waves through LDS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-        }
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups: every fragment read is done after this
-
-    // ------------------------------------------------------------------------------------ epilogue
-    // lane holds, for 16x16 tile (i, j): row m = i*16 + lane%16, columns j*16 + (lane/16)*4 + 0..3
-    {
-        const int ncol = wc * 64 + lq * 4;
+            float* Ss = reinterpret_cast<float*>(Os);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            const int n = n0 + ncol + j * 16;
-            if (a.bias != nullptr && n < a.N) bv = *reinterpret_cast<const f32x4_t*>(a.bias + n);  // N % 4 == 0
+            for (int k = 0; k < 8; ++k) csum[k] += __shfl_xor(csum[k], 32, 64);
+            if (lane < 32) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x4_t v = acc[i][j] + bv;
-                const bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                const int row = wr * 128 + i * 16 + l15;
-                *reinterpret_cast<bf16x4*>(smem + row * OPITCH + (ncol + j * 16) * 2) = pk;
+                for (int k = 0; k < 8; ++k) Ss[wave * BN + och * 8 + k] = csum[k];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < BN && on0 + tid < a.N) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) s += Ss[w * BN + tid];
+                a.colsum_slab[(long)otile_m * a.N + on0 + tid] = s;
             }
         }
-    }
-    __syncthreads();
-
-    const int och = tid & 31, orow = tid >> 5;  // 32 chunks of 8 columns per row, 16 rows per pass
-    const int ncol = n0 + och * 8;
-    const bool col_ok = ncol < a.N;  // N % 8 == 0
-    char* Cbase = static_cast<char*>(a.C) + m0 * a.ldc * 2;
-    const char* Rbase = a.residual ? static_cast<const char*>(a.residual) + m0 * a.ldr * 2 : nullptr;
-    const char* Ubase = a.gelu_in ? static_cast<const char*>(a.gelu_in) + m0 * a.ldu * 2 : nullptr;
-    char* Pbase = a.preact_out ? static_cast<char*>(a.preact_out) + m0 * a.ldc * 2 : nullptr;
-    float csum[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) csum[k] = 0.f;
-#pragma unroll 4
-    for (int p = 0; p < BM / 16; ++p) {
-        const int row = p * 16 + orow;
-        if (row < rows_m && col_ok) {
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + row * OPITCH + och * 16);
-            if (Pbase != nullptr) *reinterpret_cast<bf16x8*>(Pbase + ((long)row * a.ldc + ncol) * 2) = v;
-            if (a.act == 1) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (bf16)gelu_f((float)v[k]);
-            }
-            if (Ubase != nullptr) {
-                const bf16x8 u = *reinterpret_cast<const bf16x8*>(Ubase + ((long)row * a.ldu + ncol) * 2);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] * gelu_grad_f((float)u[k]));
-            }
-            if (Rbase != nullptr) {
-                const bf16x8 r = *reinterpret_cast<const bf16x8*>(Rbase + ((long)row * a.ldr + ncol) * 2);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)r[k]);
-            }
-            if (a.colsum_slab != nullptr) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) csum[k] += (float)v[k];
-            }
-            *reinterpret_cast<bf16x8*>(Cbase + ((long)row * a.ldc + ncol) * 2) = v;
-        }
-    }
-    if (a.colsum_slab != nullptr) {
-        // per-tile column sums of what was stored (bias gradient of the layer that produced this gradient):
-        // threads och + 32 * r own the same 8 columns: lanes l and l^32 in a wave, then the 8 waves through LDS
-        __syncthreads();
-        float* Ss = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) csum[k] += __shfl_xor(csum[k], 32, 64);
-        if (lane < 32) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) Ss[wave * BN + och * 8 + k] = csum[k];
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < a.N) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) s += Ss[w * BN + tid];
-            a.colsum_slab[(long)tile_m * a.N + n0 + tid] = s;
-        }
+        if (!has_next) break;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // staging reads done, the next K-tile 0 is visible to every wave
     }
 }
 
@@ -294,18 +362,46 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
 
 int gemm_m_tiles(long M) { return (int)((M + BM - 1) / BM); }
 
+template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED>
+static void launch_variant(const GemmArgs& a, int grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+}
+
 void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
     GemmArgs a = args;
     a.m_tiles = gemm_m_tiles(a.M);
     a.n_tiles = (a.N + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
     if (a.M <= 0 || a.N <= 0) return;
-    hipLaunchKernelGGL(k_gemm_nt, dim3(a.m_tiles * a.n_tiles), dim3(512), LDS_BYTES, s, a);
+    // 32 tiles run together on one XCD: with many tile columns walk bands of 4 tile rows (4 A panels + 8 B panels
+    // per K-step instead of 1 + 32)
+    a.group_m = a.n_tiles > 12 ? 4 : 1;
+    const int total = a.m_tiles * a.n_tiles;
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        const char* e = std::getenv("PDT_GEMM_GRID");
+        return e ? std::atoi(e) : n;
+    }();
+    const int grid = total < cus ? total : cus;
+    const bool ragged = a.K % BK != 0, colsum = a.colsum_slab != nullptr;
+    const int extra = a.residual ? 1 : (a.gelu_in ? 2 : 0);
+    const bool act = a.act == 1;
+    if ((a.residual && a.gelu_in) || (act && (extra || colsum || !a.preact_out)) || (!act && a.preact_out) ||
+        (ragged && (extra || act))) {
+        fprintf(stderr, "launch_gemm_nt: unsupported epilogue combination\n");
+        abort();
+    }
+    if (act) launch_variant<0, true, false, false>(a, grid, s);
+    else if (extra == 1) colsum ? launch_variant<1, false, true, false>(a, grid, s) : launch_variant<1, false, false, false>(a, grid, s);
+    else if (extra == 2) colsum ? launch_variant<2, false, true, false>(a, grid, s) : launch_variant<2, false, false, false>(a, grid, s);
+    else if (ragged) colsum ? launch_variant<0, false, true, true>(a, grid, s) : launch_variant<0, false, false, true>(a, grid, s);
+    else colsum ? launch_variant<0, false, true, false>(a, grid, s) : launch_variant<0, false, false, false>(a, grid, s);
 }
 
 }  // namespace pdt

@@ -213,7 +213,7 @@ struct GemmArgs {
     void* preact_out;      // [M][ldc] bf16 or null: the value before the activation is written here too
     int act;               // 0 none, 1 GELU (erf form)
     float* colsum_slab;    // [m_tiles][N] fp32 or null: per-m-tile column sums of the stored values
-    int m_tiles, n_tiles;  // filled by the launcher
+    int m_tiles, n_tiles, group_m;  // filled by the launcher
 };
 int gemm_m_tiles(long M);
 void launch_gemm_nt(const GemmArgs& a, hipStream_t s);
