@@ -576,7 +576,8 @@ std::tuple<Tensor, Tensor, Tensor> layernorm_fwd(const Tensor& x, const Tensor& 
 
 // -> (dx, dgamma, dbeta)
 std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& mean,
-                                                 const Tensor& rstd, const Tensor& gamma) {
+                                                 const Tensor& rstd, const Tensor& gamma,
+                                                 const c10::optional<Tensor>& addend) {
     TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kBFloat16 && x.is_contiguous() && x.dim() >= 2, "x: contiguous bf16");
     TORCH_CHECK(dy.is_cuda() && dy.scalar_type() == at::kBFloat16 && dy.is_contiguous() && dy.sizes() == x.sizes(),
                 "dy: contiguous bf16 with the shape of x");
@@ -585,12 +586,20 @@ std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& dy, const Tensor&
     TORCH_CHECK(reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0 && reinterpret_cast<uintptr_t>(dy.data_ptr()) % 16 == 0,
                 "x / dy must be 16-B aligned");
     check_vec_f32(gamma, D, "gamma"); check_vec_f32(mean, M, "mean"); check_vec_f32(rstd, M, "rstd");
+    const void* addp = nullptr;
+    if (addend.has_value() && addend->defined()) {
+        TORCH_CHECK(addend->is_cuda() && addend->scalar_type() == at::kBFloat16 && addend->is_contiguous() &&
+                        addend->sizes() == x.sizes() && reinterpret_cast<uintptr_t>(addend->data_ptr()) % 16 == 0,
+                    "addend: contiguous bf16 with the shape of x");
+        addp = addend->data_ptr();
+    }
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor dx = at::empty_like(x);
     const int blocks = layernorm_bwd_blocks(M);
     Tensor slab = at::empty({blocks, 2 * D}, x.options().dtype(at::kFloat));
     launch_layernorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
-                         gamma.data_ptr<float>(), dx.data_ptr(), slab.data_ptr<float>(), blocks, M, (int)D, cur_stream(x));
+                         gamma.data_ptr<float>(), dx.data_ptr(), slab.data_ptr<float>(), blocks, M, (int)D, addp,
+                         cur_stream(x));
     Tensor sums = blocks == 1 ? slab.view({2 * D}) : reduce_slab(slab, blocks, 2 * D);
     return {dx, sums.narrow(0, D, D), sums.narrow(0, 0, D)};
 }
@@ -1004,7 +1013,54 @@ Tensor linear_wgrad(const Tensor& dy, const Tensor& x) {
     return flat.view({N, K});
 }
 
+// ------------------------------------------------------------------------------------- vit glue
+// x [B,3,H,W] channels_last bf16 -> patches [B*G*G, P*P*3] in (py, px, c) order
+Tensor patchify(const Tensor& x, int64_t P) {
+    check_nhwc_bf16(x, "x");
+    const long B = x.size(0), H = x.size(2), W = x.size(3);
+    TORCH_CHECK(x.size(1) == 3 && H == W && P > 0 && P % 8 == 0 && H % P == 0, "patchify: [B,3,S,S] image, S % P == 0, P % 8 == 0");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    const long G = H / P;
+    Tensor out = at::empty({B * G * G, P * P * 3}, x.options().memory_format(at::MemoryFormat::Contiguous));
+    launch_patchify(x.data_ptr(), out.data_ptr(), B, (int)G, (int)P, cur_stream(x));
+    return out;
+}
+
+Tensor vit_embed_fwd(const Tensor& patch, const Tensor& cls, const Tensor& pos) {
+    TORCH_CHECK(patch.is_cuda() && patch.scalar_type() == at::kBFloat16 && patch.dim() == 3 && patch.is_contiguous(),
+                "patch: contiguous bf16 [B,T,D]");
+    const long B = patch.size(0), T = patch.size(1), D = patch.size(2);
+    TORCH_CHECK(D % 8 == 0 && reinterpret_cast<uintptr_t>(patch.data_ptr()) % 16 == 0, "patch: D % 8 == 0, 16-B aligned");
+    check_vec_f32(cls, D, "class_token");
+    check_vec_f32(pos, (T + 1) * D, "pos_embedding");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(patch.device());
+    Tensor out = at::empty({B, T + 1, D}, patch.options());
+    launch_vit_embed_fwd(patch.data_ptr(), cls.data_ptr<float>(), pos.data_ptr<float>(), out.data_ptr(), B, (int)T, (int)D,
+                         cur_stream(patch));
+    return out;
+}
+
+// dx [B,T+1,D] -> (dpatch [B,T,D] bf16, dpos [T+1,D] fp32)
+std::tuple<Tensor, Tensor> vit_embed_bwd(const Tensor& dx) {
+    TORCH_CHECK(dx.is_cuda() && dx.scalar_type() == at::kBFloat16 && dx.dim() == 3 && dx.is_contiguous() && dx.size(1) >= 1,
+                "dx: contiguous bf16 [B,T+1,D]");
+    const long B = dx.size(0), T = dx.size(1) - 1, D = dx.size(2);
+    TORCH_CHECK(D % 8 == 0 && reinterpret_cast<uintptr_t>(dx.data_ptr()) % 16 == 0 && B < (1L << 31), "dx: D % 8 == 0, 16-B aligned");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dx.device());
+    Tensor dpatch = at::empty({B, T, D}, dx.options());
+    const int slices = (int)std::max<long>(1, std::min<long>(16, B / 8));
+    Tensor slab = at::empty({slices, (T + 1) * D}, dx.options().dtype(at::kFloat));
+    if (B == 0) return {dpatch, at::zeros({T + 1, D}, slab.options())};
+    launch_vit_embed_bwd(dx.data_ptr(), dpatch.data_ptr(), slab.data_ptr<float>(), (int)B, (int)T, (int)D, slices,
+                         cur_stream(dx));
+    Tensor dpos = slices == 1 ? slab.view({T + 1, D}) : reduce_slab(slab, slices, (T + 1) * D).view({T + 1, D});
+    return {dpatch, dpos};
+}
+
 void bind_ops(pybind11::module& m) {
+    m.def("patchify", &patchify);
+    m.def("vit_embed_fwd", &vit_embed_fwd);
+    m.def("vit_embed_bwd", &vit_embed_bwd);
     m.def("gemm_nt", &gemm_nt, pybind11::arg("a"), pybind11::arg("b"), pybind11::arg("bias") = pybind11::none(),
           pybind11::arg("residual") = pybind11::none(), pybind11::arg("gelu_in") = pybind11::none(),
           pybind11::arg("act") = 0, pybind11::arg("want_preact") = false, pybind11::arg("want_colsum") = false);
@@ -1033,7 +1089,8 @@ void bind_ops(pybind11::module& m) {
     m.def("attention_fwd", &attention_fwd);
     m.def("attention_bwd", &attention_bwd);
     m.def("layernorm_fwd", &layernorm_fwd);
-    m.def("layernorm_bwd", &layernorm_bwd);
+    m.def("layernorm_bwd", &layernorm_bwd, pybind11::arg("dy"), pybind11::arg("x"), pybind11::arg("mean"),
+          pybind11::arg("rstd"), pybind11::arg("gamma"), pybind11::arg("addend") = pybind11::none());
     m.def("maxpool3x3s2_fwd", &maxpool3x3s2_fwd);
     m.def("maxpool3x3s2_bwd", &maxpool3x3s2_bwd);
     m.def("bn_relu_maxpool_fwd", &bn_relu_maxpool_fwd);

@@ -24,7 +24,7 @@ ARCH = "gfx950"
 
 HIP_SOURCES = [
     "kernels/elementwise.hip", "kernels/softmax_ce.hip", "kernels/bn.hip", "kernels/layernorm.hip", "kernels/attention.hip", "kernels/pool.hip",
-    "kernels/gemm.hip", "kernels/conv_igemm.hip", "kernels/conv_wgrad.hip", "kernels/conv_wgrad_win.hip", "kernels/conv_stem.hip",
+    "kernels/gemm.hip", "kernels/vit.hip", "kernels/conv_igemm.hip", "kernels/conv_wgrad.hip", "kernels/conv_wgrad_win.hip", "kernels/conv_stem.hip",
     "comm/ipc_allreduce.hip",
 ]
 CPP_SOURCES = ["binding/ops.cpp", "binding/module.cpp", "comm/rccl_comm.cpp", "comm/ipc_allreduce.cpp", "reducer/reducer.cpp"]

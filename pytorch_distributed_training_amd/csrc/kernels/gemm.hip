@@ -384,7 +384,7 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
     const int total = a.m_tiles * a.n_tiles;
     static const int cus = [] {
         int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
         const char* e = std::getenv("PDT_GEMM_GRID");
         return e ? std::atoi(e) : n;
     }();

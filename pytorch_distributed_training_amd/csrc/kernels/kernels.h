@@ -103,7 +103,8 @@ void launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, 
                           long M, int D, float eps, hipStream_t s);
 // slab: fp32 [blocks][2][D] = per-block partial [dbeta, dgamma]
 void launch_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                          void* dx, float* slab, int blocks, long M, int D, hipStream_t s);
+                          void* dx, float* slab, int blocks, long M, int D, const void* addend /* or null */,
+                          hipStream_t s);
 
 // ---- fused self-attention, head_dim 64, S <= 256 (attention.hip) -----------------------------------
 bool attention_shape_ok(int S, int head_dim);
@@ -217,6 +218,15 @@ struct GemmArgs {
 };
 int gemm_m_tiles(long M);
 void launch_gemm_nt(const GemmArgs& a, hipStream_t s);
+
+// ---- ViT glue (vit.hip) -----------------------------------------------------------------------------------
+// x NHWC bf16 [B][G*P][G*P][3] -> patches [B*G*G][P*P*3] in (py, px, c) order; P % 8 == 0
+void launch_patchify(const void* x, void* out, long B, int G, int P, hipStream_t s);
+// out [B][T+1][D] = cat(cls, patch) + pos      (cls [D], pos [T+1][D] fp32; D % 8 == 0)
+void launch_vit_embed_fwd(const void* patch, const float* cls, const float* pos, void* out, long B, int T, int D,
+                          hipStream_t s);
+// dx [B][T+1][D] -> dpatch [B][T][D], slab [slices][T+1][D] fp32 partial batch sums of dx
+void launch_vit_embed_bwd(const void* dx, void* dpatch, float* slab, int B, int T, int D, int slices, hipStream_t s);
 
 // ---- 3-channel stem (conv_stem.hip) -----------------------------------------------------------
 // x NHWC bf16 [B,H,W,3] -> xp [B][H+6][W+8][4] (image at row +3 / col +4, zeros elsewhere, channel 3 = 0)

@@ -67,7 +67,8 @@ template <int NP>
 __global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                 const float* __restrict__ gamma, bf16* __restrict__ dx,
-                                                float* __restrict__ slab /*[gridDim.x][2][D]*/, long M) {
+                                                float* __restrict__ slab /*[gridDim.x][2][D]*/, long M,
+                                                const bf16* __restrict__ addend /* or null: added to dx */) {
     constexpr int D = NP * 256;
     __shared__ float red[3][2][D];  // waves 1..3 park their column sums here
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -105,11 +106,20 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, con
         }
         const float c1 = wave_sum(s1) * (1.f / D), c2 = wave_sum(s2) * (1.f / D);
         bf16x4* ox = reinterpret_cast<bf16x4*>(dx + row * D);
+        // the gradient that reaches the same tensor through the residual connection joins here (pre-LN
+        // transformer block: d(x) = d(skip) + LN'(d(branch))) instead of in a separate elementwise add
+        const bf16x4* ar = addend ? reinterpret_cast<const bf16x4*>(addend + row * D) : nullptr;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             bf16x4 o;
+            if (ar) {
+                const bf16x4 ta = ar[lane + 64 * j];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (bf16)(rs * (gg[j][k] - c1 - xh[j][k] * c2));
+                for (int k = 0; k < 4; ++k) o[k] = (bf16)(rs * (gg[j][k] - c1 - xh[j][k] * c2) + (float)ta[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (bf16)(rs * (gg[j][k] - c1 - xh[j][k] * c2));
+            }
             ox[lane + 64 * j] = o;
         }
     }
@@ -167,9 +177,9 @@ void launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, 
 }
 
 void launch_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                          void* dx, float* slab, int blocks, long M, int D, hipStream_t s) {
+                          void* dx, float* slab, int blocks, long M, int D, const void* addend, hipStream_t s) {
     PDT_LN_DISPATCH(D, hipLaunchKernelGGL((k_ln_bwd<NP>), dim3(blocks), dim3(256), 0, s, (const bf16*)dy,
-                                          (const bf16*)x, mean, rstd, gamma, (bf16*)dx, slab, M));
+                                          (const bf16*)x, mean, rstd, gamma, (bf16*)dx, slab, M, (const bf16*)addend));
 }
 
 }  // namespace pdt

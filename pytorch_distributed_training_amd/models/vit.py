@@ -7,8 +7,9 @@ BASELINE.json config 5: "ViT-B/16 DDP bf16 (GEMM-heavy path, fused softmax-CE
 ``...mlp.{0,3}.{weight,bias}``, ``encoder.ln.*``, ``heads.head.*``.
 
 197 tokens per image: ordinary single-device attention, no sequence
-parallelism.  The projections / MLP are plain GEMMs and go to
-the library (hipBLASLt); loss and optimizer are the fused HIP kernels.
+parallelism.  Projections, MLP, patch embedding and head run on
+the own MFMA GEMM (csrc/kernels/gemm.hip) with bias / GELU / residual fused in
+its epilogues; loss and optimizer are the fused HIP kernels.
 """
 from __future__ import annotations
 
@@ -17,10 +18,9 @@ from collections import OrderedDict
 
 import torch
 import torch.nn as tnn
-import torch.nn.functional as tF
 
 from .. import nn as pnn
-from ..nn.functional import attention, layer_norm
+from ..nn.functional import attention, layer_norm, linear, mlp_gelu, patch_embed, vit_embed
 
 
 class MultiheadSelfAttention(tnn.Module):
@@ -36,18 +36,17 @@ class MultiheadSelfAttention(tnn.Module):
         tnn.init.xavier_uniform_(self.in_proj_weight)
         tnn.init.zeros_(self.out_proj.bias)
 
-    def forward(self, x):
-        b, s, d = x.shape
-        w, bias = self.in_proj_weight, self.in_proj_bias
-        if w.dtype != x.dtype:
-            qkv = pnn.modules._LowpLinearFn.apply(x, w, bias, getattr(w, "_lp", None))
-        else:
-            qkv = tF.linear(x, w, bias)
+    def forward(self, x, residual=None):
+        qkv = linear(x, self.in_proj_weight, self.in_proj_bias)   # own MFMA GEMM, bias in the epilogue
         out = attention(qkv, self.num_heads)  # [b, s, d]: fused kernel on GPU/bf16, matmul-softmax oracle elsewhere
-        return self.out_proj(out)
+        return self.out_proj(out, residual)   # bias + residual in the GEMM epilogue
 
 
 class EncoderBlock(tnn.Module):
+    """Pre-LN block.  Every elementwise op rides in a GEMM or LayerNorm kernel: bias / GELU / residual add in GEMM
+    epilogues, GELU' in the data-gradient GEMM's epilogue, and the two gradients that meet at a residual fork are
+    summed inside the LayerNorm backward kernel (``layer_norm(..., with_skip=True)``)."""
+
     def __init__(self, dim, heads, mlp_dim, dropout=0.0):
         super().__init__()
         self.ln_1 = tnn.LayerNorm(dim, eps=1e-6)
@@ -61,13 +60,18 @@ class EncoderBlock(tnn.Module):
             tnn.init.normal_(m.bias, std=1e-6)
 
     @staticmethod
-    def _ln(ln, x):
-        return layer_norm(x, ln.weight, ln.bias, ln.eps)
+    def _ln(ln, x, with_skip=False):
+        return layer_norm(x, ln.weight, ln.bias, ln.eps, with_skip)
 
     def forward(self, x):
-        y = self.dropout(self.self_attention(self._ln(self.ln_1, x)))
-        x = x + y
-        return x + self.mlp(self._ln(self.ln_2, x))
+        if self.dropout.p > 0.0 and self.training:  # unfused composition (the reference configuration uses p = 0)
+            y = self.dropout(self.self_attention(self._ln(self.ln_1, x)))
+            x = x + y
+            return x + self.mlp(self._ln(self.ln_2, x))
+        xn, skip = self._ln(self.ln_1, x, True)
+        x = self.self_attention(xn, skip)
+        xn, skip = self._ln(self.ln_2, x, True)
+        return mlp_gelu(xn, self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight, self.mlp[3].bias, skip)
 
 
 class Encoder(tnn.Module):
@@ -79,9 +83,12 @@ class Encoder(tnn.Module):
             (f"encoder_layer_{i}", EncoderBlock(dim, heads, mlp_dim, dropout)) for i in range(layers)))
         self.ln = tnn.LayerNorm(dim, eps=1e-6)
 
-    def forward(self, x):
-        x = x + self.pos_embedding.to(x.dtype)
+    def forward(self, x, cls_only: bool = False):
+        """``x`` already carries the position embedding.  ``cls_only``: normalise just the class-token row (LayerNorm
+        is row-wise, and the classifier reads nothing else)."""
         x = self.layers(self.dropout(x))
+        if cls_only:
+            x = x[:, 0]
         return EncoderBlock._ln(self.ln, x)
 
 
@@ -103,22 +110,12 @@ class VisionTransformer(tnn.Module):
         tnn.init.zeros_(self.heads.head.bias)
 
     def forward(self, x):
-        b = x.shape[0]
-        # patch embedding: a stride = kernel conv is a GEMM over unfolded patches ([b*tokens, 3*p*p] x W^T);
-        # it goes to the plain library GEMM instead of a convolution library
-        p, g = self.patch_size, self.image_size // self.patch_size
-        patches = x.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
-        w = self.conv_proj.weight
-        w2 = w.reshape(self.hidden_dim, -1)
-        w_lp = getattr(w, "_lp", None)
-        if w.dtype != patches.dtype:
-            x = pnn.modules._LowpLinearFn.apply(patches, w2, self.conv_proj.bias,
-                                               None if w_lp is None else w_lp.reshape(self.hidden_dim, -1))
-        else:
-            x = tF.linear(patches, w2, self.conv_proj.bias)  # [b, tokens, dim]
-        x = torch.cat([self.class_token.to(x.dtype).expand(b, -1, -1), x], dim=1)
-        x = self.encoder(x)
-        return self.heads(x[:, 0])
+        # patch embedding: a stride = kernel conv is a GEMM over the extracted patches; then class token +
+        # position embedding in one pass
+        tok = patch_embed(x, self.conv_proj.weight, self.conv_proj.bias, self.patch_size)  # [b, tokens, dim]
+        x = vit_embed(tok, self.class_token, self.encoder.pos_embedding)
+        x = self.encoder(x, cls_only=True)
+        return self.heads(x)
 
 
 def vit_b_16(num_classes=1000, image_size=224, **kw):

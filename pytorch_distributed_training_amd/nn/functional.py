@@ -422,8 +422,12 @@ def attention(qkv, heads: int):
 
 # ---------------------------------------------------------------- layernorm
 class _LayerNormFn(torch.autograd.Function):
+    """``(y, skip)``: ``skip`` (when requested) is the input passed through, to be used as the residual branch of a
+    pre-LN transformer block.  Its gradient then arrives HERE and is added inside the LayerNorm backward kernel
+    instead of autograd summing two activation-sized tensors with a separate elementwise add."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, with_skip):
         be = backend_for(x)
         if be is not reference:
             why = be.layernorm_unsupported_reason(x)
@@ -435,20 +439,201 @@ class _LayerNormFn(torch.autograd.Function):
         y, mean, rstd = be.layernorm_fwd(x, g32, b32, eps)
         ctx.save_for_backward(x, mean, rstd, g32)
         ctx.cfg = (be, gamma.dtype, beta.dtype)
-        return y
+        ctx.set_materialize_grads(False)
+        return y, (x.view_as(x) if with_skip else None)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, mean, rstd, g32 = ctx.saved_tensors
+        be, gdt, bdt = ctx.cfg
+        if dy is None:
+            return dskip, None, None, None, None
+        dx, dgamma, dbeta = be.layernorm_bwd(dy, x, mean, rstd, g32, dskip)
+        return dx, dgamma.to(gdt), dbeta.to(bdt), None, None
+
+
+def layer_norm(x, weight, bias, eps: float = 1e-5, with_skip: bool = False):
+    """LayerNorm over the last dimension: one read + one write of the activation in its own dtype, fp32
+    statistics (HIP kernel on bf16 GPU tensors, PyTorch fp32 oracle elsewhere).  ``with_skip=True`` returns
+    ``(y, x_skip)``: use ``x_skip`` as the block's residual input (see ``_LayerNormFn``)."""
+    y, skip = _LayerNormFn.apply(x, weight, bias, float(eps), bool(with_skip))
+    return (y, skip) if with_skip else y
+
+
+# ------------------------------------------------------------------- linear
+def _lowp_weight(w, dtype):
+    lp = getattr(w, "_lp", None)
+    if lp is not None and lp.dtype == dtype:
+        return lp
+    return w if w.dtype == dtype else w.to(dtype)
+
+
+class _LinearFn(torch.autograd.Function):
+    """``y = x @ w^T + b (+ residual)`` on the MFMA GEMM (csrc/kernels/gemm.hip; /root/reference/main.py:40's ``fc`` and
+    every ViT projection): bias and residual ride in the epilogue; backward is one GEMM against the cached
+    transposed weight, the transposing split-K weight-gradient kernel (fp32 result for the fp32 master weight) and a
+    streaming column sum for the bias."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, wk, residual, be):
+        k = x.shape[-1]
+        x2 = x.reshape(-1, k)
+        res2 = None if residual is None else residual.reshape(-1, wk.shape[0])
+        y, _, _ = be.gemm_nt(x2, wk, bias, res2)
+        ctx.save_for_backward(x2, wk)
+        ctx.cfg = (be, w.dtype, None if bias is None else bias.dtype, tuple(x.shape), residual is not None)
+        return y.view(*x.shape[:-1], wk.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x, mean, rstd, g32 = ctx.saved_tensors
-        be, gdt, bdt = ctx.cfg
-        dx, dgamma, dbeta = be.layernorm_bwd(dy, x, mean, rstd, g32)
-        return dx, dgamma.to(gdt), dbeta.to(bdt), None
+        x2, wk = ctx.saved_tensors
+        be, wdt, bdt, x_shape, has_res = ctx.cfg
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = be.gemm_nt(dy2, be.weight_t(wk))[0].view(x_shape)
+        if ctx.needs_input_grad[1]:
+            dw = be.linear_wgrad(dy2, x2).to(wdt)
+        if bdt is not None and ctx.needs_input_grad[2]:
+            db = be.colsum(dy2.contiguous()).to(bdt)
+        dres = dy if (has_res and ctx.needs_input_grad[4]) else None
+        return dx, dw, db, None, dres, None
 
 
-def layer_norm(x, weight, bias, eps: float = 1e-5):
-    """LayerNorm over the last dimension: one read + one write of the activation in its own dtype, fp32
-    statistics (HIP kernel on bf16 GPU tensors, PyTorch fp32 oracle elsewhere)."""
-    return _LayerNormFn.apply(x, weight, bias, float(eps))
+def linear(x, weight, bias=None, residual=None):
+    """``x @ weight^T + bias (+ residual)``; ``weight`` may be an fp32 master with a bf16 working copy (``_lp``)."""
+    be = backend_for(x)
+    if be is not reference:
+        wk = _lowp_weight(weight, x.dtype)
+        why = be.linear_unsupported_reason(x, wk)
+        if why is None:
+            return _LinearFn.apply(x, weight, bias, wk, residual, be)
+        _note_fallback("linear", why)
+    if weight.dtype != x.dtype or x.dtype != torch.float32:
+        # low-precision compute against an fp32 master: the oracle GEMM (fp32 math, fp32 weight / bias gradients)
+        return _LinearFn.apply(x, weight, bias, _lowp_weight(weight, x.dtype), residual, reference)
+    y = torch.nn.functional.linear(x, weight, bias)
+    return y if residual is None else y + residual
+
+
+class _MlpGeluFn(torch.autograd.Function):
+    """``y = gelu(x @ w0^T + b0) @ w1^T + b1 (+ residual)``: the transformer MLP as ONE node, so that no GELU or add
+    kernel remains.  Forward: GELU (and the pre-activation the backward needs) in the first GEMM's epilogue, bias +
+    residual in the second's.  Backward: the data gradient of the second layer is multiplied by GELU'(u) in ITS
+    epilogue, which also reduces the first layer's bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, wk0, wk1, residual, be):
+        x2 = x.reshape(-1, x.shape[-1])
+        h, u, _ = be.gemm_nt(x2, wk0, b0, None, None, 1, True)
+        res2 = None if residual is None else residual.reshape(-1, wk1.shape[0])
+        y, _, _ = be.gemm_nt(h, wk1, b1, res2)
+        ctx.save_for_backward(x2, u, h, wk0, wk1)
+        ctx.cfg = (be, w0.dtype, w1.dtype, None if b0 is None else b0.dtype, None if b1 is None else b1.dtype,
+                   tuple(x.shape), residual is not None)
+        return y.view(*x.shape[:-1], wk1.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, h, wk0, wk1 = ctx.saved_tensors
+        be, w0dt, w1dt, b0dt, b1dt, x_shape, has_res = ctx.cfg
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dw1 = be.linear_wgrad(dy2, h).to(w1dt)
+        db1 = be.colsum(dy2.contiguous()).to(b1dt) if b1dt is not None else None
+        du, _, db0 = be.gemm_nt(dy2, be.weight_t(wk1), None, None, u, 0, False, True)
+        dw0 = be.linear_wgrad(du, x2).to(w0dt)
+        dx = be.gemm_nt(du, be.weight_t(wk0))[0].view(x_shape) if ctx.needs_input_grad[0] else None
+        db0 = db0.to(b0dt) if b0dt is not None else None
+        dres = dy if (has_res and ctx.needs_input_grad[7]) else None
+        return dx, dw0, db0, dw1, db1, None, None, dres, None
+
+
+def mlp_gelu(x, w0, b0, w1, b1, residual=None):
+    be = backend_for(x)
+    wk0, wk1 = _lowp_weight(w0, x.dtype), _lowp_weight(w1, x.dtype)
+    if be is not reference:
+        why = be.linear_unsupported_reason(x, wk0) or be.linear_unsupported_reason(x, wk1)
+        if why is not None:
+            _note_fallback("mlp_gelu", why)
+            be = reference
+    if be is reference and x.dtype == torch.float32 and w0.dtype == torch.float32:
+        y = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(x, w0, b0)), w1, b1)
+        return y if residual is None else y + residual
+    return _MlpGeluFn.apply(x, w0, b0, w1, b1, wk0, wk1, residual, be)
+
+
+# ----------------------------------------------------------------- vit glue
+class _PatchEmbedFn(torch.autograd.Function):
+    """A ``kernel = stride = p`` convolution of the image (ViT ``conv_proj``) as patch extraction + ONE GEMM.  Patches
+    and weight both use the (py, px, c) element order, which is the physical order of the channels_last weight and
+    of p*3 contiguous image elements, so neither operand is re-laid-out."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, wk2, p, be):
+        b = x.shape[0]
+        patches = be.patchify(x, p)
+        y, _, _ = be.gemm_nt(patches, wk2, bias)
+        ctx.save_for_backward(patches)
+        ctx.cfg = (be, tuple(w.shape), w.dtype, None if bias is None else bias.dtype)
+        return y.view(b, -1, wk2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (patches,) = ctx.saved_tensors
+        be, w_shape, wdt, bdt = ctx.cfg
+        d, c, p, _ = w_shape
+        dy2 = dy.reshape(-1, d)
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = be.linear_wgrad(dy2, patches).to(wdt).view(d, p, p, c).permute(0, 3, 1, 2)
+        if bdt is not None and ctx.needs_input_grad[2]:
+            db = be.colsum(dy2.contiguous()).to(bdt)
+        return None, dw, db, None, None, None
+
+
+def patch_embed(x, weight, bias, p: int):
+    """``conv2d(x, weight, bias, stride=p)`` for ``kernel_size == p`` -> tokens ``[B, (S/p)^2, D]``"""
+    be = backend_for(x)
+    d = weight.shape[0]
+    if be is not reference:
+        wk = _lowp_weight(weight, x.dtype)
+        wk2 = be.as_matrix_param(wk, d)
+        why = be.patchify_unsupported_reason(x, p) or be.linear_unsupported_reason(x, wk2)
+        if why is None:
+            return _PatchEmbedFn.apply(x, weight, bias, wk2, p, be)
+        _note_fallback("patch_embed", why)
+    if x.dtype != weight.dtype:
+        wk = _lowp_weight(weight, x.dtype)
+        return _PatchEmbedFn.apply(x, weight, bias, reference.as_matrix_param(wk, d), p, reference)
+    y = torch.nn.functional.conv2d(x, weight, bias, stride=p)
+    return y.flatten(2).transpose(1, 2)
+
+
+class _VitEmbedFn(torch.autograd.Function):
+    """``cat(class_token, tokens) + pos_embedding`` in one pass (and one pass backward: token gradient copy + the
+    batch sums that are the position-embedding / class-token gradients)."""
+
+    @staticmethod
+    def forward(ctx, tokens, cls, pos, be):
+        ctx.cfg = (be, cls.dtype, pos.dtype, tuple(cls.shape), tuple(pos.shape))
+        return be.vit_embed_fwd(tokens, cls, pos)
+
+    @staticmethod
+    def backward(ctx, dx):
+        be, cdt, pdt_, cshape, pshape = ctx.cfg
+        dtok, dpos = be.vit_embed_bwd(dx)
+        return (dtok if ctx.needs_input_grad[0] else None, dpos[0].to(cdt).view(cshape), dpos.to(pdt_).view(pshape), None)
+
+
+def vit_embed(tokens, class_token, pos_embedding):
+    be = backend_for(tokens)
+    if be is not reference and (tokens.dtype != torch.bfloat16 or tokens.shape[-1] % 8):
+        _note_fallback("vit_embed", f"{tokens.dtype} width {tokens.shape[-1]}")
+        be = reference
+    if be is reference and tokens.dtype == class_token.dtype:
+        b = tokens.shape[0]
+        return torch.cat([class_token.expand(b, -1, -1), tokens], dim=1) + pos_embedding
+    return _VitEmbedFn.apply(tokens, class_token, pos_embedding, be)
 
 
 # -------------------------------------------------------------------- pools

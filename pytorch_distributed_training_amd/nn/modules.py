@@ -14,7 +14,6 @@ from __future__ import annotations
 import torch
 import torch.distributed as tdist
 import torch.nn as tnn
-import torch.nn.functional as tF
 
 from . import functional as F
 from ..ops import backend_for
@@ -38,43 +37,12 @@ class Conv2d(tnn.Conv2d):
 
 
 class Linear(tnn.Linear):
-    """fc layers go to the library GEMM (hipBLASLt through ``F.linear``): a plain
-    GEMM is exactly what the library is for; the fused hot ops are ours."""
+    """``forward(x, residual=None)``: ``x @ W^T + b (+ residual)`` on the own MFMA GEMM (csrc/kernels/gemm.hip) with
+    bias and residual in its epilogue for bf16 GPU tensors (fp32 master weight, bf16 working copy ``weight._lp``);
+    the PyTorch oracle on CPU tensors."""
 
-    def forward(self, x):
-        w = self.weight
-        lp = getattr(w, "_lp", None)
-        if lp is not None and lp.dtype == x.dtype and not torch.is_grad_enabled():
-            return tF.linear(x, lp, None if self.bias is None else self.bias.to(x.dtype))
-        if w.dtype != x.dtype:
-            return _LowpLinearFn.apply(x, w, self.bias, lp if (lp is not None and lp.dtype == x.dtype) else None)
-        return tF.linear(x, w, self.bias)
-
-
-class _LowpLinearFn(torch.autograd.Function):
-    """bf16 GEMMs, fp32 master weight: weight/bias grads come out in fp32 directly."""
-
-    @staticmethod
-    def forward(ctx, x, w, bias, w_lp):
-        wk = w_lp if w_lp is not None else w.to(x.dtype)
-        ctx.save_for_backward(x, wk)
-        ctx.has_bias = bias is not None
-        ctx.wdt = w.dtype
-        return tF.linear(x, wk, None if bias is None else bias.to(x.dtype))
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, wk = ctx.saved_tensors
-        dx = dw = db = None
-        dy2 = dy.reshape(-1, dy.shape[-1])
-        x2 = x.reshape(-1, x.shape[-1])
-        if ctx.needs_input_grad[0]:
-            dx = (dy2 @ wk).view_as(x)
-        if ctx.needs_input_grad[1]:
-            dw = (dy2.t() @ x2).to(ctx.wdt)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = backend_for(dy2).colsum(dy2).to(ctx.wdt)  # fp32 accumulation in one streaming pass
-        return dx, dw, db, None
+    def forward(self, x, residual=None):
+        return F.linear(x, self.weight, self.bias, residual)
 
 
 class BatchNorm2d(tnn.BatchNorm2d):

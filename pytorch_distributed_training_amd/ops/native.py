@@ -226,9 +226,92 @@ def layernorm_fwd(x, gamma, beta, eps: float):
     return _C.layernorm_fwd(x.contiguous(), gamma.contiguous(), beta.contiguous(), eps)
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma):
-    """-> (dx, dgamma, dbeta)"""
-    return _C.layernorm_bwd(dy.contiguous(), x, mean, rstd, gamma.contiguous())
+def layernorm_bwd(dy, x, mean, rstd, gamma, addend=None):
+    """-> (dx, dgamma, dbeta); ``addend`` (shape of x) is added to dx in the same pass"""
+    return _C.layernorm_bwd(dy.contiguous(), x, mean, rstd, gamma.contiguous(),
+                            None if addend is None else addend.contiguous())
+
+
+# ------------------------------------------------------------------- linear
+def linear_unsupported_reason(x, w):
+    """``x [..., K]`` against ``w [N, K]``: why the MFMA GEMM (csrc/kernels/gemm.hip) cannot take it, or None"""
+    if x.dtype != _BF16 or w.dtype != _BF16:
+        return f"dtype {x.dtype}/{w.dtype} (native GEMM is bf16)"
+    n, k = w.shape
+    if k % 8 or n % 8:
+        return f"features {k}->{n} not multiples of 8"
+    return None
+
+
+def _mat(t):
+    """2-D view with contiguous 16-B-aligned rows (copies only when it has to)"""
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.stride(1) != 1 or t2.stride(0) % 8 or t2.data_ptr() % 16:
+        t2 = t2.contiguous()
+    return t2
+
+
+def gemm_nt(a, w, bias=None, residual=None, gelu_in=None, act: int = 0, want_preact: bool = False,
+            want_colsum: bool = False):
+    """``epilogue(a @ w^T)`` on the matrix cores -> ``(c, preact, colsum)``; a ``[M, K]``, w ``[N, K]`` bf16.
+    bias fp32 (added before the rounding), ``act=1`` GELU, ``residual`` added last, ``gelu_in``: the result is
+    multiplied by GELU'(gelu_in); ``colsum``: fp32 column sums of ``c``."""
+    b32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float()).contiguous()
+    return _C.gemm_nt(_mat(a), _mat(w), b32, None if residual is None else _mat(residual),
+                      None if gelu_in is None else _mat(gelu_in), act, want_preact, want_colsum)
+
+
+def linear_wgrad(dy, x):
+    """fp32 ``dy^T @ x`` -> ``[N, K]``"""
+    return _C.linear_wgrad(dy.reshape(-1, dy.shape[-1]).contiguous(), x.reshape(-1, x.shape[-1]).contiguous())
+
+
+def weight_t(w):
+    """``w^T`` as a contiguous ``[K, N]`` bf16 matrix (the K-contiguous operand of the data-gradient GEMM); cached per
+    weights epoch for parameters, refreshed together with the conv weights in one multi-tensor launch"""
+    n, k = w.shape
+    w4 = getattr(w, "_pdt_w4", None)
+    if w4 is None:
+        w4 = w.view(n, k, 1, 1)
+        if getattr(w, "_pdt_param", False):
+            w4._pdt_param = True
+            w._pdt_w4 = w4
+    return _transposed(w4).view(k, n)
+
+
+def as_matrix_param(w, n: int):
+    """``[n, kh*kw*cin]`` matrix in (kh, kw, cin) order of a conv weight (the patch embedding's weight as a GEMM
+    operand): a view for channels_last storage; the view of a parameter's working copy keeps its identity across
+    steps so that its transpose stays cached"""
+    v = getattr(w, "_pdt_2d", None)
+    if v is None:
+        v = w.permute(0, 2, 3, 1).reshape(n, -1)
+        if getattr(w, "_pdt_param", False) and v.data_ptr() == w.data_ptr():
+            v._pdt_param = True
+            w._pdt_2d = v
+    return v
+
+
+# ----------------------------------------------------------------- vit glue
+def patchify(x, p: int):
+    """channels_last bf16 image ``[B,3,S,S]`` -> ``[B*(S/p)^2, p*p*3]`` patches in (py, px, c) order"""
+    return _C.patchify(x, p)
+
+
+def patchify_unsupported_reason(x, p: int):
+    if x.dtype != _BF16 or not _is_cl(x) or x.shape[1] != 3 or p % 8 or x.shape[2] != x.shape[3] or x.shape[2] % p:
+        return f"image {tuple(x.shape)} {x.dtype} patch {p}"
+    return None
+
+
+def vit_embed_fwd(patch, cls, pos):
+    """``cat(cls, patch) + pos`` -> ``[B, T+1, D]``"""
+    return _C.vit_embed_fwd(patch.contiguous(), cls.reshape(-1).float().contiguous(), pos.reshape(-1).float().contiguous())
+
+
+def vit_embed_bwd(dx):
+    """-> (dpatch [B,T,D], dpos [T+1,D] fp32); the class-token gradient is ``dpos[0]``"""
+    return _C.vit_embed_bwd(dx.contiguous())
 
 
 # -------------------------------------------------------------------- pools

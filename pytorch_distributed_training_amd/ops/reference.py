@@ -179,7 +179,7 @@ def layernorm_fwd(x, gamma, beta, eps: float):
     return y.to(x.dtype), mean.reshape(-1), rstd.reshape(-1)
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma):
+def layernorm_bwd(dy, x, mean, rstd, gamma, addend=None):
     d = x.shape[-1]
     xf, dyf = x.float().reshape(-1, d), dy.float().reshape(-1, d)
     xhat = (xf - mean[:, None]) * rstd[:, None]
@@ -187,6 +187,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma):
     c1 = g.mean(-1, keepdim=True)
     c2 = (g * xhat).mean(-1, keepdim=True)
     dx = rstd[:, None] * (g - c1 - xhat * c2)
+    if addend is not None:
+        dx = dx + addend.float().reshape(-1, d)
     return dx.to(x.dtype).view_as(x), (dyf * xhat).sum(0), dyf.sum(0)
 
 
@@ -240,6 +242,64 @@ def softmax_ce_fwd_bwd(logits, labels):
 
 
 # ---------------------------------------------------------------- linear ---
+def linear_unsupported_reason(x, w):
+    return None
+
+
+def gemm_nt(a, w, bias=None, residual=None, gelu_in=None, act: int = 0, want_preact: bool = False,
+            want_colsum: bool = False):
+    """Oracle of csrc/kernels/gemm.hip: fp32 math, every intermediate rounded where the kernel rounds it"""
+    a2, w2 = a.reshape(-1, a.shape[-1]), w.reshape(-1, w.shape[-1])
+    dt = a.dtype
+    c = a2.float() @ w2.float().t()
+    if bias is not None:
+        c = c + bias.float()
+    c = c.to(dt)
+    pre = c if want_preact else None
+    if act == 1:
+        c = F.gelu(c.float()).to(dt)
+    if gelu_in is not None:
+        u = gelu_in.reshape(c.shape).float()
+        cdf = 0.5 * (1.0 + torch.erf(u * 0.7071067811865476))
+        pdf = torch.exp(-0.5 * u * u) * 0.3989422804014327
+        c = (c.float() * (cdf + u * pdf)).to(dt)
+    if residual is not None:
+        c = (c.float() + residual.reshape(c.shape).float()).to(dt)
+    return c, pre, (c.float().sum(0) if want_colsum else None)
+
+
+def linear_wgrad(dy, x):
+    return dy.reshape(-1, dy.shape[-1]).float().t() @ x.reshape(-1, x.shape[-1]).float()
+
+
+def weight_t(w):
+    return w.t().contiguous()
+
+
+def as_matrix_param(w, n: int):
+    return w.permute(0, 2, 3, 1).reshape(n, -1)
+
+
+def patchify(x, p: int):
+    b, c, h, w = x.shape
+    g = h // p
+    return x.permute(0, 2, 3, 1).reshape(b, g, p, g, p, c).permute(0, 1, 3, 2, 4, 5).reshape(b * g * g, p * p * c)
+
+
+def patchify_unsupported_reason(x, p: int):
+    return None
+
+
+def vit_embed_fwd(patch, cls, pos):
+    b, t, d = patch.shape
+    x = torch.cat([cls.reshape(1, 1, d).float().expand(b, 1, d), patch.float()], 1) + pos.reshape(1, t + 1, d).float()
+    return x.to(patch.dtype)
+
+
+def vit_embed_bwd(dx):
+    return dx[:, 1:].contiguous(), dx.float().sum(0)
+
+
 def linear_fwd(x, w, bias):
     return F.linear(x, w.to(x.dtype), None if bias is None else bias.to(x.dtype))
 
