@@ -83,6 +83,110 @@ def test_colsum_kernel(kc, shape):
     _assert_all_ok(kc, n)
 
 
+@pytest.fixture(scope="module")
+def gc():
+    pdt.require_native()
+    sys.path.insert(0, os.path.join(ROOT, "bench", "micro"))
+    import gemm_check
+
+    return gemm_check
+
+
+@pytest.mark.parametrize("mnk", [(256, 256, 64), (300, 264, 128), (17, 8, 72), (513, 1000, 2048), (1000, 512, 1000),
+                                 (2 * 197, 2304, 768), (70000, 256, 192)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_gemm_plain_and_bias(gc, mnk, bias):
+    """csrc/kernels/gemm.hip vs fp32 matmul: ragged M / N / K, several tiles per persistent workgroup (70000 rows =
+    274 tiles on 256 CUs), per-element relative error"""
+    assert gc.check(*mnk, bias=bias, timing=False)
+
+
+@pytest.mark.parametrize("kw", [dict(bias=True, act=1, preact=True), dict(bias=True, residual=True),
+                                dict(gelu_in=True, colsum=True), dict(colsum=True), dict(residual=True, colsum=True)])
+@pytest.mark.parametrize("mnk", [(777, 520, 192), (66000, 768, 128)])
+def test_gemm_fused_epilogues(gc, mnk, kw):
+    """GELU + pre-activation, residual add, GELU' multiply and the column-sum reduction of the GEMM epilogue"""
+    assert gc.check(*mnk, timing=False, **kw)
+
+
+def test_gemm_identity_weight_asymmetric_input():
+    """A = asymmetric integers, B = I: the output must be A (catches a transposed accumulator map or swapped operands)"""
+    ext = pdt.require_native()
+    m, k = 300, 256
+    a = (torch.arange(m * k, device="cuda", dtype=torch.float32).reshape(m, k) % 251 - 125).to(torch.bfloat16)
+    eye = torch.eye(k, device="cuda", dtype=torch.bfloat16)
+    c = ext.gemm_nt(a, eye)[0]
+    assert torch.equal(c, a)
+
+
+def test_linear_wgrad_and_vit_glue_kernels():
+    ext = pdt.require_native()
+    from pytorch_distributed_training_amd.ops import native, reference
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dy = torch.randn(3 * 197, 1000, device="cuda", generator=g).to(torch.bfloat16)
+    x = torch.randn(3 * 197, 768, device="cuda", generator=g).to(torch.bfloat16)
+    dw = native.linear_wgrad(dy, x)
+    ref = dy.float().t() @ x.float()
+    assert dw.dtype == torch.float32 and ((dw - ref).abs() / (ref.abs() + ref.abs().mean())).max() < 1e-3
+    img = torch.randn(3, 3, 64, 64, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert torch.equal(native.patchify(img, 16), reference.patchify(img, 16))
+    tok = torch.randn(5, 16, 768, device="cuda", generator=g).to(torch.bfloat16)
+    cls, pos = torch.randn(1, 1, 768, device="cuda", generator=g), torch.randn(1, 17, 768, device="cuda", generator=g)
+    assert (native.vit_embed_fwd(tok, cls, pos).float() - reference.vit_embed_fwd(tok, cls, pos).float()).abs().max() < 2e-2
+    dxx = torch.randn(19, 17, 768, device="cuda", generator=g).to(torch.bfloat16)
+    dp, dpos = native.vit_embed_bwd(dxx)
+    rp, rpos = reference.vit_embed_bwd(dxx)
+    assert torch.equal(dp, rp) and (dpos - rpos).abs().max() < 1e-3
+    # LayerNorm backward with the fused residual-gradient addend
+    xx = torch.randn(100, 768, device="cuda", generator=g).to(torch.bfloat16)
+    gam, bet = torch.randn(768, device="cuda", generator=g), torch.randn(768, device="cuda", generator=g)
+    y, mean, rstd = native.layernorm_fwd(xx, gam, bet, 1e-6)
+    dyy, add = torch.randn_like(xx), torch.randn_like(xx)
+    dx1 = native.layernorm_bwd(dyy, xx, mean, rstd, gam, add)[0]
+    dx2 = reference.layernorm_bwd(dyy, xx, mean, rstd, gam, add)[0]
+    assert (dx1.float() - dx2.float()).abs().max() < 5e-2
+
+
+def test_vit_native_matches_fp32_oracle_gradients():
+    """One ViT step (2 layers, width 768) on the fused bf16 nodes against the same weights run through the fp32
+    PyTorch oracles: loss and every parameter gradient must agree (cosine), none skipped."""
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.models.vit import VisionTransformer
+    from pytorch_distributed_training_amd.nn import CrossEntropyLoss
+
+    torch.manual_seed(0)
+    net = VisionTransformer(64, 16, 2, 12, 768, 3072, 1000).cuda()
+    for p in net.parameters():  # zero-initialised heads / tokens would make half the gradients trivially zero
+        if p.abs().sum() == 0:
+            torch.nn.init.normal_(p, std=0.02)
+    ref = VisionTransformer(64, 16, 2, 12, 768, 3072, 1000).cuda()
+    ref.load_state_dict(net.state_dict())
+    for p in net.parameters():
+        p._lp = p.detach().to(torch.bfloat16)
+        ref_p = dict(ref.named_parameters())
+    for (n, p) in net.named_parameters():
+        ref_p[n].data.copy_(p._lp.float())  # the oracle runs on the SAME bf16-rounded weights
+    x = torch.randn(6, 3, 64, 64, device="cuda")
+    y = torch.randint(0, 1000, (6,), device="cuda")
+    crit = CrossEntropyLoss()
+    xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    loss = crit(net(xb), y)
+    loss.backward()
+    ops.set_force_reference(True)
+    try:
+        loss_ref = crit(ref(xb.float()), y)
+        loss_ref.backward()
+    finally:
+        ops.set_force_reference(False)
+    assert abs(float(loss) - float(loss_ref)) < 3e-2 * max(1.0, abs(float(loss_ref)))
+    for (n, p) in net.named_parameters():
+        g, gr = p.grad.float().flatten(), ref_p[n].grad.float().flatten()
+        cos = torch.nn.functional.cosine_similarity(g, gr, dim=0).item()
+        assert cos > 0.98, (n, cos)
+        assert 0.9 < (g.norm() / gr.norm().clamp_min(1e-12)).item() < 1.1, n
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 32), (3, 64, 48), (4, 224, 224)])
 def test_stem_conv_native_fwd_wgrad(kc, shape):
     n = len(kc.RESULTS)
