@@ -155,14 +155,9 @@ def main(argv=None) -> int:
         }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
-    sync()
-    if env.world_size > 1 and on_gpu:
-        # every rank is past the last collective: leave without running communicator destructors, so a rank
-        # that is slow to tear down can never hold the job (the launcher only needs the exit codes)
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
-    pdist.destroy_process_group()
+    sys.stdout.flush()
+    # ordered teardown (barrier -> reducer hooks off -> communicator drained and destroyed -> c10d), bounded by a timer
+    pdist.shutdown(engine, timeout_s=60.0)
     return 0
 
 

@@ -74,11 +74,13 @@ def get_parser() -> argparse.ArgumentParser:
     p.add_argument("--seed", default=None, type=int)
     p.add_argument("--graph", dest="graph", action="store_const", const="on", default="auto",
                    help="capture forward+backward+optimizer of the steady-state step in one hipGraph (default: auto "
-                        "= on for a single-process GPU run on launch-bound images of at most 64x64, off otherwise; "
-                        "multi-GPU capture is opt-in)")
+                        "= on for GPU runs on launch-bound images of at most 64x64, off otherwise)")
     p.add_argument("--no_graph", dest="graph", action="store_const", const="off", help="never capture a hipGraph")
     p.add_argument("--eval", action="store_true", help="run the top-1 evaluation after training (main.py:119-130)")
     p.add_argument("--summary_json", default=None, type=str)
+    p.add_argument("--debug_replicas", action="store_true",
+                   help="debug mode: reducer launch-order / completion-event assertions and a replica checksum "
+                        "all-gather after every step (PDT_DEBUG_REPLICAS_EVERY=N: every N steps)")
     p.add_argument("--log_dir", default=".", type=str)
     return p
 
@@ -104,7 +106,9 @@ def main(argv=None) -> int:
     timer = metrics.StepTimer()
 
     # CIFAR-shaped steps are ~550 kernels of a few microseconds: launch-bound, 1.7x faster replayed from a hipGraph
-    use_graph = args.graph == "on" or (args.graph == "auto" and env.device.type == "cuda" and world_size == 1
+    # (multi-rank capture: the step then contains the bucket all-reduces on the communicator's stream; a captured
+    # step with ncclAllReduce replays bit-identically, tests/test_gpu.py::test_hip_graph_with_rccl_allreduce_...)
+    use_graph = args.graph == "on" or (args.graph == "auto" and env.device.type == "cuda"
                                        and max(trainset.sample_shape[1:]) <= 64)
     with profiling.make_profiler(args.profile, job_id) as prof:
         engine = Engine(EngineConfig(
@@ -115,11 +119,24 @@ def main(argv=None) -> int:
             # that the trace shows real kernels and no collection is active while the stream is being captured
             graph_warmup=12 if args.profile == "torch" else 3,
             image_size=trainset.sample_shape[1]))
-        start_epoch, global_step = 0, 0
+        start_epoch, global_step, resume_batches = 0, 0, 0
         if args.resume:
             st = ckpt.load_checkpoint(args.resume, engine.net, engine.optimizer, sampler)
             start_epoch, global_step = st["epoch"], st["global_step"]
+            # mid-epoch checkpoint (--checkpoint_every): continue the epoch where it stopped instead of replaying
+            # its first part (the samples of this rank's shard that were already consumed are skipped ONCE)
+            consumed = int(st["extra"].get("samples_in_epoch", 0))
+            if consumed > 0:
+                if int(st["extra"].get("batch_size", batch_size)) != batch_size or \
+                        int(st["extra"].get("world_size", world_size)) != world_size:
+                    raise SystemExit("--resume of a mid-epoch checkpoint needs the batch size and world size it was "
+                                     "written with")
+                train_loader.start_sample = consumed
+                resume_batches = consumed // batch_size
         start_step = global_step
+        if args.debug_replicas:
+            engine.net.check_replicas = True
+            engine.net.reducer.set_debug(True)
         # per-bucket all-reduce timing for the JSON summary (needs the native RCCL communicator; timed events
         # cannot be recorded while a hipGraph is captured)
         comm_timing = bool(args.summary_json) and not use_graph and hasattr(engine.net.reducer, "set_timing") \
@@ -130,7 +147,8 @@ def main(argv=None) -> int:
         sync_mark = None  # (global_step, wall time) right after a device sync, past the warm-up steps
         for e in range(start_epoch, epochs):
             sampler.set_epoch(e)
-            for idx, (imgs, labels) in enumerate(train_loader):
+            first_idx, resume_batches = (resume_batches if e == start_epoch else 0), 0
+            for idx, (imgs, labels) in enumerate(train_loader, start=first_idx):
                 start = time.time()
                 global_step += 1
                 loss = engine.train_step(imgs, labels)
@@ -148,12 +166,20 @@ def main(argv=None) -> int:
                         torch.cuda.synchronize()
                     sync_mark = (global_step, time.time())
                 if args.checkpoint and args.checkpoint_every and global_step % args.checkpoint_every == 0:
-                    ckpt.save_checkpoint(args.checkpoint, engine.net, engine.optimizer, e, global_step, sampler)
+                    ckpt.save_checkpoint(args.checkpoint, engine.net, engine.optimizer, e, global_step, sampler,
+                                         extra={"samples_in_epoch": (idx + 1) * batch_size, "batch_size": batch_size,
+                                                "world_size": world_size})
                 if args.steps is not None and global_step >= args.steps:
                     done = True
                     break
             if args.checkpoint:
-                ckpt.save_checkpoint(args.checkpoint, engine.net, engine.optimizer, e + 1, global_step, sampler)
+                if done and (idx + 1) < len(train_loader):
+                    # stopped by --steps inside the epoch: the checkpoint describes that position, not the epoch's end
+                    ckpt.save_checkpoint(args.checkpoint, engine.net, engine.optimizer, e, global_step, sampler,
+                                         extra={"samples_in_epoch": (idx + 1) * batch_size, "batch_size": batch_size,
+                                                "world_size": world_size})
+                else:
+                    ckpt.save_checkpoint(args.checkpoint, engine.net, engine.optimizer, e + 1, global_step, sampler)
             if done:
                 break
         if torch.cuda.is_available():
@@ -171,6 +197,7 @@ def main(argv=None) -> int:
 
         s = timer.summary(batch_size * world_size)
         s.update({"world_size": world_size, "batch_size": batch_size, "model": args.model, "dataset": args.dataset,
+                  "dataset_class": type(trainset).__name__,
                   "dtype": str(engine.dtype), "reducer": engine.net.reducer_kind,
                   "native_extension": pdt.native_available(),
                   "library_fallbacks": dict(pF.fallback_counts),
@@ -188,7 +215,7 @@ def main(argv=None) -> int:
                 s["comm"] = {"error": str(e)}
         metrics.write_json(args.summary_json, s)
     log.close()
-    pdist.destroy_process_group()
+    pdist.shutdown(engine)  # ordered: barrier, reducer hooks off, communicators drained + destroyed, c10d
     return 0
 
 

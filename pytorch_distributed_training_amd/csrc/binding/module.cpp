@@ -53,7 +53,10 @@ PYBIND11_MODULE(_C, m) {
              }, py::call_guard<py::gil_scoped_release>())
         .def("synchronize", &pdt::RcclComm::synchronize, py::call_guard<py::gil_scoped_release>())
         .def("async_error", &pdt::RcclComm::async_error)
-        .def("abort", &pdt::RcclComm::abort);
+        .def("abort", &pdt::RcclComm::abort)
+        // ordered teardown: stop the watchdog, drain the communicator's stream, ncclCommDestroy (idempotent)
+        .def("close", &pdt::RcclComm::close, py::call_guard<py::gil_scoped_release>())
+        .def_property_readonly("closed", &pdt::RcclComm::closed);
 
     py::class_<pdt::IpcAllReduce, std::shared_ptr<pdt::IpcAllReduce>>(m, "IpcAllReduce")
         .def(py::init([](int rank, int world, int device, int cap, double timeout_s) {
@@ -101,6 +104,11 @@ PYBIND11_MODULE(_C, m) {
         .def("remove_hooks", &pdt::Reducer::remove_hooks)
         .def("install_hooks", &pdt::Reducer::install_hooks)
         .def("set_timing", &pdt::Reducer::set_timing)
+        .def("set_debug", &pdt::Reducer::set_debug)
+        .def("set_roctx", &pdt::Reducer::set_roctx)
+        .def_property_readonly("debug", &pdt::Reducer::debug)
+        .def("launch_log", &pdt::Reducer::launch_log)
+        .def("debug_checks", &pdt::Reducer::debug_checks)
         .def("comm_stats", &pdt::Reducer::comm_stats, py::call_guard<py::gil_scoped_release>());
 
     m.def("plan_buckets", [](std::vector<int64_t> numels, std::vector<int64_t> order, int64_t elem, int64_t cap,

@@ -59,13 +59,20 @@ RcclComm::RcclComm(int rank, int world_size, const std::string& unique_id, int d
     if (!(wd && std::string(wd) == "0")) watchdog_ = std::thread([this] { watchdog_loop(); });
 }
 
-RcclComm::~RcclComm() {
+void RcclComm::close() {
     stop_ = true;
-    if (watchdog_.joinable()) watchdog_.join();
-    if (comm_ && !aborted_) {
-        hipStreamSynchronize(stream_);
-        ncclCommDestroy(comm_);
+    if (watchdog_.joinable()) watchdog_.join();  // no thread may poll a communicator that is being destroyed
+    if (comm_) {
+        if (!aborted_) {
+            hipStreamSynchronize(stream_);
+            ncclCommDestroy(comm_);
+        }
+        comm_ = nullptr;
     }
+}
+
+RcclComm::~RcclComm() {
+    close();
     if (ev_) hipEventDestroy(ev_);
     if (stream_) hipStreamDestroy(stream_);
 }
@@ -87,6 +94,7 @@ void RcclComm::watchdog_loop() {
 }
 
 std::string RcclComm::async_error() {
+    if (!comm_) return "communicator closed";
     ncclResult_t async = ncclSuccess;
     ncclResult_t r = ncclCommGetAsyncError(comm_, &async);
     if (r != ncclSuccess) return ncclGetErrorString(r);
@@ -103,21 +111,25 @@ void RcclComm::abort() {
 
 void RcclComm::all_reduce_sum(at::Tensor& t, hipStream_t s) {
     check_tensor(t);
+    TORCH_CHECK(comm_, "RcclComm: collective on a closed communicator");
     PDT_NCCL(ncclAllReduce(t.data_ptr(), t.data_ptr(), (size_t)t.numel(), nccl_type(t.scalar_type()), ncclSum, comm_,
                            s ? s : stream_));
 }
 void RcclComm::broadcast(at::Tensor& t, int root, hipStream_t s) {
     check_tensor(t);
+    TORCH_CHECK(comm_, "RcclComm: collective on a closed communicator");
     PDT_NCCL(ncclBroadcast(t.data_ptr(), t.data_ptr(), (size_t)t.numel(), nccl_type(t.scalar_type()), root, comm_,
                            s ? s : stream_));
 }
 void RcclComm::reduce_sum(at::Tensor& t, int root, hipStream_t s) {
     check_tensor(t);
+    TORCH_CHECK(comm_, "RcclComm: collective on a closed communicator");
     PDT_NCCL(ncclReduce(t.data_ptr(), t.data_ptr(), (size_t)t.numel(), nccl_type(t.scalar_type()), ncclSum, root,
                         comm_, s ? s : stream_));
 }
 void RcclComm::all_gather(const at::Tensor& src, at::Tensor& dst, hipStream_t s) {
     check_tensor(src);
+    TORCH_CHECK(comm_, "RcclComm: collective on a closed communicator");
     check_tensor(dst);
     TORCH_CHECK(dst.numel() == src.numel() * world_ && dst.scalar_type() == src.scalar_type(), "all_gather size mismatch");
     PDT_NCCL(ncclAllGather(src.data_ptr(), dst.data_ptr(), (size_t)src.numel(), nccl_type(src.scalar_type()), comm_,

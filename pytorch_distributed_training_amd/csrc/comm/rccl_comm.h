@@ -42,6 +42,10 @@ class RcclComm {
     void synchronize();
     std::string async_error();  // "" when healthy
     void abort();
+    // Ordered teardown, callable before the destructor (and idempotent): 1. stop and join the watchdog thread,
+    // 2. drain the communicator's stream, 3. ncclCommDestroy.  Every rank calls it after its last collective.
+    void close();
+    bool closed() const { return comm_ == nullptr; }
 
    private:
     void watchdog_loop();

@@ -6,6 +6,10 @@
 #include <torch/csrc/autograd/utils/lambda_post_hook.h>
 #include <torch/csrc/distributed/c10d/Types.hpp>
 
+#include <dlfcn.h>
+
+#include <cstdlib>
+
 #include "../binding/binding.h"
 
 namespace pdt {
@@ -16,6 +20,35 @@ namespace {
         hipError_t _e = (expr);                                                      \
         TORCH_CHECK(_e == hipSuccess, "HIP error: ", hipGetErrorString(_e), " (" #expr ")"); \
     } while (0)
+// roctx through dlopen: the markers are optional, the extension must load on a box without the profiler SDK
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char* name : {"libroctx64.so", "/opt/rocm/lib/libroctx64.so", "librocprofiler-sdk-roctx.so"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+            }
+        }
+        push = nullptr;
+        pop = nullptr;
+    }
+};
+Roctx& roctx() {
+    static Roctx r;
+    return r;
+}
+struct RoctxRange {
+    bool on;
+    RoctxRange(bool enabled, const std::string& msg) : on(enabled && roctx().push != nullptr) {
+        if (on) roctx().push(msg.c_str());
+    }
+    ~RoctxRange() {
+        if (on) roctx().pop();
+    }
+};
 }  // namespace
 
 Reducer::Reducer(std::vector<at::Tensor> params, std::vector<std::string> names, std::shared_ptr<RcclComm> rccl,
@@ -40,8 +73,19 @@ Reducer::Reducer(std::vector<at::Tensor> params, std::vector<std::string> names,
     std::vector<int64_t> order;
     for (int64_t i = (int64_t)params_.size() - 1; i >= 0; --i) order.push_back(i);
     build(order);
+    const char* dbg = std::getenv("PDT_DEBUG_REDUCER");
+    debug_ = dbg && dbg[0] == '1';
 
     install_hooks();
+}
+
+void Reducer::set_debug(bool on) {
+    std::lock_guard<std::mutex> g(mu_);
+    debug_ = on;
+}
+void Reducer::set_roctx(bool on) {
+    std::lock_guard<std::mutex> g(mu_);
+    roctx_ = on;
 }
 
 void Reducer::install_hooks() {
@@ -123,6 +167,7 @@ void Reducer::prepare_for_backward() {
     }
     next_bucket_ = 0;
     callback_queued_ = false;
+    launch_log_.clear();
     if (!rebuilt_) ready_order_.clear();
 }
 
@@ -152,6 +197,19 @@ void Reducer::launch_ready() {
 }
 
 void Reducer::launch(Bucket& b) {
+    const size_t bidx = (size_t)(&b - buckets_.data());
+    if (debug_) {
+        // plan order, once, and only with every gradient in (the zero-fill of finalize is the one exception)
+        TORCH_CHECK(bidx == next_bucket_, "reducer debug: bucket ", bidx, " launched out of plan order (expected ", next_bucket_, ")");
+        TORCH_CHECK(!b.launched, "reducer debug: bucket ", bidx, " launched twice in one iteration");
+        TORCH_CHECK(in_finalize_ || b.pending == 0, "reducer debug: bucket ", bidx, " launched with ", b.pending, " gradients missing");
+        for (size_t j = 0; j < b.ready.size() && !in_finalize_; ++j)
+            TORCH_CHECK(b.ready[j], "reducer debug: bucket ", bidx, " slot ", j, " (", names_[b.plan.params[j]], ") not ready");
+        ++debug_checks_;
+    }
+    launch_log_.push_back((int64_t)bidx);
+    RoctxRange range(roctx_, "pdt.bucket" + std::to_string(bidx) + ".allreduce[" +
+                                 std::to_string(b.plan.numel * (int64_t)c10::elementSize(grad_dtype_)) + "B]");
     const double scale = 1.0 / (double)world_;
     std::vector<at::Tensor> srcs, dsts;
     for (size_t j = 0; j < b.plan.params.size(); ++j) {
@@ -192,6 +250,7 @@ void Reducer::launch(Bucket& b) {
             rccl_->all_reduce_sum(b.flat);        // overlaps the rest of backward
             if (timing_) PDT_HIP(hipEventRecord(b.t1, rccl_->stream()));
             PDT_HIP(hipEventRecord(b.done, rccl_->stream()));
+            b.done_iter = iteration_;
         } else {
             std::vector<at::Tensor> ts{b.flat};
             c10d::AllreduceOptions opts;
@@ -206,10 +265,24 @@ void Reducer::finalize() {
     std::lock_guard<std::mutex> g(mu_);
     callback_queued_ = false;
     if (!require_sync_) return;
+    RoctxRange range(roctx_, "pdt.reducer.finalize");
     // parameters that never produced a gradient are zero-filled and their buckets launched now
+    in_finalize_ = true;
     while (next_bucket_ < buckets_.size()) {
         launch(buckets_[next_bucket_]);
         ++next_bucket_;
+    }
+    in_finalize_ = false;
+    if (debug_) {
+        for (size_t bi = 0; bi < buckets_.size(); ++bi) {
+            TORCH_CHECK(buckets_[bi].launched, "reducer debug: bucket ", bi, " was never launched");
+            if (rccl_ && is_cuda_)
+                TORCH_CHECK(buckets_[bi].done_iter == iteration_, "reducer debug: bucket ", bi,
+                            " has no completion event from this iteration");
+        }
+        TORCH_CHECK(launch_log_.size() == buckets_.size(), "reducer debug: ", launch_log_.size(), " launches for ",
+                    buckets_.size(), " buckets");
+        ++debug_checks_;
     }
     if (rccl_ || pg_) {
         if (rccl_ && is_cuda_) {
@@ -220,6 +293,15 @@ void Reducer::finalize() {
                 timed_ = true;
             }
             for (auto& b : buckets_) PDT_HIP(hipStreamWaitEvent(compute, b.done, 0));
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (debug_ && hipStreamIsCapturing(compute, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+                // event order: once the compute stream has drained, every all-reduce it waited for must be complete
+                PDT_HIP(hipStreamSynchronize(compute));
+                for (size_t bi = 0; bi < buckets_.size(); ++bi)
+                    TORCH_CHECK(hipEventQuery(buckets_[bi].done) == hipSuccess, "reducer debug: bucket ", bi,
+                                " all-reduce still pending after the compute stream waited for it");
+                ++debug_checks_;
+            }
         } else {
             for (auto& b : buckets_)
                 if (b.work) {

@@ -57,6 +57,17 @@ class Reducer {
     // (per-bucket all-reduce ms, ms the compute stream had to wait after backward, ms from the first all-reduce's
     // start to the last one's end) of the most recent iteration; synchronises with the communicator's stream.
     std::tuple<std::vector<double>, double, double> comm_stats();
+    // Debug mode ("the reducer is where races live"): every launch asserts that buckets go out in plan
+    // order, exactly once, with every gradient slot marked ready (or the launch coming from finalize's zero-fill);
+    // finalize asserts that every bucket was launched and, on the GPU path, that every completion event was
+    // recorded this iteration and has really completed once the compute stream has waited for it.  Also keeps
+    // the launch sequence of the last iteration for tests.  Costs one stream synchronisation per step.
+    void set_debug(bool on);
+    bool debug() const { return debug_; }
+    std::vector<int64_t> launch_log() const { return launch_log_; }
+    int64_t debug_checks() const { return debug_checks_; }
+    // roctx range (rocprofv3 --marker-trace) around every bucket's flatten + all-reduce enqueue and around finalize
+    void set_roctx(bool on);
 
    private:
     struct Bucket {
@@ -69,6 +80,7 @@ class Reducer {
         hipEvent_t done = nullptr;
         hipEvent_t t0 = nullptr, t1 = nullptr;  // timing mode only
         bool launched = false;
+        int64_t done_iter = -1;  // iteration in which `done` was last recorded (debug mode)
     };
     void build(const std::vector<int64_t>& order);
     void destroy_buckets();
@@ -90,6 +102,9 @@ class Reducer {
     bool rebuilt_ = false;
     bool callback_queued_ = false;
     bool timing_ = false, timed_ = false;
+    bool debug_ = false, roctx_ = false, in_finalize_ = false;
+    int64_t debug_checks_ = 0;
+    std::vector<int64_t> launch_log_;
     hipEvent_t bwd_end_ = nullptr;
     int64_t iteration_ = 0;
     size_t next_bucket_ = 0;

@@ -16,6 +16,7 @@ calls; the reference's per-sample PIL path is CPU-bound).
 from __future__ import annotations
 
 import os
+import sys
 
 import numpy as np
 import torch
@@ -135,11 +136,28 @@ def build_dataset(name: str, train: bool = True, root: str = "dataset", num_clas
                   length: int | None = None, seed: int = 0):
     name = name.lower()
     if name in ("cifar100", "cifar-100"):
-        try:
+        path = os.path.join(root, "cifar-100-binary", "train.bin" if train else "test.bin")
+        found = os.path.exists(path)
+        # every rank must train on the same source: agree on "every rank has the files" (one MIN all-reduce), so a
+        # node without them turns the whole job to the synthetic set instead of silently feeding different data
+        import torch.distributed as tdist
+
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+            dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
+            flag = torch.tensor([1 if found else 0], dtype=torch.int32, device=dev)
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+            everywhere = bool(flag.item())
+            if found and not everywhere:
+                sys.stderr.write(f"[pdt] {path} exists here but not on every rank: all ranks use synthetic data\n")
+            found = everywhere
+        if found:
             return CIFAR100Binary(root, train)
-        except FileNotFoundError:
-            # same shapes, dtypes and length as the reference's dataset
-            return SyntheticCIFAR(train, num_classes or 100, length, seed=seed)
+        if not tdist.is_initialized() or tdist.get_rank() == 0:
+            sys.stderr.write(f"[pdt] NOTICE: {path} not found (no network to download CIFAR-100): using SYNTHETIC "
+                             f"CIFAR-100-shaped data; results are not CIFAR-100 results\n")
+            sys.stderr.flush()
+        # same shapes, dtypes and length as the reference's dataset
+        return SyntheticCIFAR(train, num_classes or 100, length, seed=seed)
     if name in ("synthetic-cifar", "synthetic_cifar"):
         return SyntheticCIFAR(train, num_classes or 100, length, seed=seed)
     if name in ("synthetic-cifar10", "synthetic_cifar10"):

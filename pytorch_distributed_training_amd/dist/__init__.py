@@ -149,6 +149,51 @@ def destroy_process_group() -> None:
     _ENV = None
 
 
+def shutdown(engine=None, timeout_s: float = 60.0) -> None:
+    """Ordered end of a (multi-rank) job, every step bounded by one watchdog timer:
+
+    1. barrier: every rank is past its last collective;
+    2. ``engine.close()``: reducer hooks off, device synchronised, the native communicator closed
+       (watchdog thread joined -> communicator stream drained -> ``ncclCommDestroy``);
+    3. any other native communicator of this process closed the same way;
+    4. ``destroy_process_group()`` (c10d's own communicators and the store).
+
+    If a peer died and a step blocks, the timer ends this process with exit code 3 after ``timeout_s`` instead of
+    holding the launcher (which tears the group down on the first non-zero exit)."""
+    import threading
+
+    done = threading.Event()
+
+    def _bail():
+        if not done.wait(timeout_s):
+            import sys
+
+            print(f"[pdt] shutdown did not finish within {timeout_s:.0f} s; exiting", file=sys.stderr, flush=True)
+            os._exit(3)
+
+    t = threading.Thread(target=_bail, name="pdt-shutdown-timer", daemon=True)
+    t.start()
+    try:
+        barrier()
+        if engine is not None:
+            engine.close()
+        try:
+            from ..parallel.reducer_native import close_all_comms
+
+            close_all_comms()
+        except ImportError:
+            pass
+        try:
+            from ..parallel import ipc
+
+            ipc.close_all()
+        except (ImportError, AttributeError):
+            pass
+        destroy_process_group()
+    finally:
+        done.set()
+
+
 def reduce_loss(tensor: torch.Tensor, rank: int, world_size: int) -> None:
     """``main.py:16-20``: SUM-reduce to rank 0, rank 0 divides by world size.
 

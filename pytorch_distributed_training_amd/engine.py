@@ -11,6 +11,7 @@ cast + NCHW->NHWC fused in one kernel, SyncBN on its own communicator.
 """
 from __future__ import annotations
 
+import os
 import sys
 from dataclasses import dataclass
 
@@ -46,6 +47,9 @@ class EngineConfig:
     # the CIFAR-shaped reference config issues ~550 kernels of a few microseconds each per step)
     graph: bool = False
     graph_warmup: int = 3
+    # SURVEY 5.2 debug mode: reducer launch-order / event assertions + a replica checksum every N steps
+    check_replicas: bool = False
+    check_replicas_every: int = 1
 
 
 def compute_dtype(cfg: EngineConfig, device: torch.device) -> torch.dtype:
@@ -85,7 +89,11 @@ class Engine:
             net, device_ids=dev_ids, output_device=dev_ids[0] if dev_ids else None,
             bucket_cap_mb=cfg.bucket_cap_mb, broadcast_buffers=cfg.broadcast_buffers,
             grad_dtype={"fp32": None, "bf16": torch.bfloat16}[cfg.grad_dtype],
-            compute_dtype=self.dtype, reducer=cfg.reducer)
+            compute_dtype=self.dtype, reducer=cfg.reducer, check_replicas=cfg.check_replicas)
+        self._check_every = max(1, int(os.environ.get("PDT_DEBUG_REPLICAS_EVERY", cfg.check_replicas_every)))
+        self._steps = 0
+        if profiling.roctx_enabled():
+            self.net.reducer.set_roctx(True)
         self.net.train()
         self._graph = None          # (CUDAGraph, static_imgs, static_labels, static_loss)
         self._graph_key = None
@@ -112,8 +120,20 @@ class Engine:
         """One iteration in the reference's order; returns the local loss tensor
         (fp32 scalar on the device, not synchronised with the host)."""
         if self.cfg.graph and self.device.type == "cuda" and self._graph_failed is None:
-            return self._graph_step(imgs, labels)
-        return self._eager_step(imgs, labels)
+            loss = self._graph_step(imgs, labels)
+        else:
+            loss = self._eager_step(imgs, labels)
+        self._steps += 1
+        if self.net.check_replicas and self._steps % self._check_every == 0:
+            self.net.assert_replicas_equal()  # raises on the first diverged step instead of training on garbage
+        return loss
+
+    def close(self) -> None:
+        """Ordered teardown of the replica (call before ``dist.shutdown``)."""
+        self._graph = None
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self.net.close()
 
     def _graph_step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         """Replay the captured step when the batch has the captured shape; run eagerly otherwise (warm-up
@@ -125,7 +145,10 @@ class Engine:
             s_labels.copy_(labels, non_blocking=True)
             g.replay()
             return s_loss
-        if self._graph is None and self._eager_steps >= self.cfg.graph_warmup and self.net._require_sync:
+        # capture only a steady-state step: past the warm-up, gradients synchronised, and the reducer's one-off bucket
+        # rebuild (start of iteration 2) behind us, so the captured launch sequence is the one every later step has
+        if (self._graph is None and self._eager_steps >= self.cfg.graph_warmup and self.net._require_sync
+                and getattr(self.net.reducer, "rebuilt", True)):
             try:
                 self._capture(imgs, labels, key)
                 return self._graph[3]

@@ -46,10 +46,32 @@ def _parse_nnodes(value: str) -> int:
 
 
 def _gpu_count() -> int:
+    """Visible GPUs WITHOUT touching the HIP runtime in this process: the launcher forks + execs every worker, and
+    an exec out of a process that has initialised the GPU is refused on some pools (and leaks /dev/kfd state into
+    the children).  Order: the visibility variables, then the KFD topology in sysfs, then a short-lived child."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    topo = "/sys/class/kfd/kfd/topology/nodes"
     try:
-        import torch
-
-        return torch.cuda.device_count()
+        n = 0
+        for node in os.listdir(topo):
+            try:
+                with open(os.path.join(topo, node, "properties")) as fh:
+                    props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:  # CPU nodes report 0 SIMDs
+                    n += 1
+            except (OSError, ValueError):
+                continue
+        if n > 0:
+            return n
+    except OSError:
+        pass
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
     except Exception:
         return 0
 

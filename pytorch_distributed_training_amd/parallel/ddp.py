@@ -90,6 +90,7 @@ class DistributedDataParallel(tnn.Module):
             bns = [m for m in module.modules() if isinstance(m, tnn.modules.batchnorm._BatchNorm)]
             from ..nn.modules import SyncBatchNorm
             broadcast_buffers = any(not isinstance(m, (SyncBatchNorm, tnn.SyncBatchNorm)) for m in bns)
+        self._all_sync_bn = not bool(broadcast_buffers)  # replicas then compute identical running statistics
         self.broadcast_buffers = bool(broadcast_buffers) and self.world_size > 1
 
         self.bucket_autotune = None
@@ -118,6 +119,8 @@ class DistributedDataParallel(tnn.Module):
                                      gradient_as_bucket_view, names)
         self.reducer_kind = kind
         self._require_sync = True
+        if self.check_replicas or os.environ.get("PDT_DEBUG_REDUCER", "0") == "1":
+            self.reducer.set_debug(True)
 
     def _autotune_bucket_cap(self, dtype) -> float:
         """``bucket_cap_mb="auto"``: time the all-reduce of a few bucket sizes on THIS job's links (xGMI ring
@@ -177,13 +180,26 @@ class DistributedDataParallel(tnn.Module):
 
     @torch.no_grad()
     def assert_replicas_equal(self) -> None:
-        """Debug aid: every rank must hold bit-identical parameters."""
-        for flat in self.param_arena.flat_tensors():
+        """Debug aid: every rank must hold bit-identical parameters (and buffers when they are kept
+        in sync).  One 8-byte all-gather per arena; ``check_replicas=True`` / ``PDT_DEBUG_REPLICAS=1`` makes the
+        engine call it every ``PDT_DEBUG_REPLICAS_EVERY`` (default 1) steps."""
+        arenas = [("parameters", f) for f in self.param_arena.flat_tensors()]
+        if self.broadcast_buffers or self._all_sync_bn:
+            arenas += [("buffers", f) for f in self.buffer_arena.flat_tensors()]
+        for what, flat in arenas:
             s = flat.double().sum().item()
-            h = int(flat.view(torch.uint8).to(torch.int64).sum().item())
+            b = flat.contiguous().view(torch.uint8).to(torch.int64)
+            # position-weighted byte sum: a swap of two values does not cancel
+            w = (torch.arange(b.numel(), device=b.device, dtype=torch.int64) % 8191) + 1
+            h = int((b * w).sum().item()) & 0x7FFFFFFFFFFFFFFF
             sums = self.comm.all_gather_i64(h, self.device)
             if len(set(sums)) != 1:
-                raise AssertionError(f"replica divergence: byte-sums {sums} (rank {self.rank} sum {s})")
+                raise AssertionError(f"replica divergence in the {what} arena ({flat.dtype}): checksums {sums} "
+                                     f"(rank {self.rank}, sum {s})")
+
+    def close(self) -> None:
+        """Ordered teardown: hooks off, the reducer's communicator drained and destroyed."""
+        self.reducer.close()
 
     def __del__(self):
         try:

@@ -75,6 +75,15 @@ def _rccl_or_none(process_group, world: int, device):
     return None
 
 
+def close_all_comms() -> None:
+    """``RcclComm.close()`` on every communicator this process created (stop watchdog -> drain stream ->
+    ncclCommDestroy); call after the last collective and before ``destroy_process_group``."""
+    for comm in list(_shared_comm.values()):
+        if comm is not None:
+            comm.close()
+    _shared_comm.clear()
+
+
 class NativeReducer:
     def __init__(self, params, comm, bucket_cap_bytes: int, first_bucket_bytes: int, grad_dtype=None,
                  gradient_as_bucket_view: bool = True, names=None, process_group=None):
@@ -143,6 +152,27 @@ class NativeReducer:
         """Recreate the AccumulateGrad nodes under the CURRENT stream (they remember the stream they were
         created on; a hipGraph capture must not pull the default stream in through them)."""
         self._r.install_hooks()
+
+    # -- debug mode / markers (SURVEY 5.1, 5.2) -----------------------------------------------------------
+    def set_debug(self, on: bool) -> None:
+        """Bucket launch-order / readiness / completion-event assertions in the C++ reducer (also PDT_DEBUG_REDUCER=1)"""
+        self._r.set_debug(bool(on))
+
+    def set_roctx(self, on: bool) -> None:
+        """one roctx range per bucket all-reduce (and around finalize), emitted from C++"""
+        self._r.set_roctx(bool(on))
+
+    def launch_log(self) -> list[int]:
+        return list(self._r.launch_log())
+
+    def debug_checks(self) -> int:
+        return int(self._r.debug_checks())
+
+    def close(self) -> None:
+        """Ordered teardown of this reducer's side of the job: hooks off, communicator drained and destroyed."""
+        self._r.remove_hooks()
+        if self.rccl is not None:
+            self.rccl.close()
 
     # -- per-bucket all-reduce timing (SURVEY 5.5) ------------------------------------------------------
     def set_timing(self, on: bool) -> bool:

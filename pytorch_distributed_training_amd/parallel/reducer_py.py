@@ -61,6 +61,25 @@ class PyReducer:
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i))
                        for i, p in enumerate(self.params) if p.requires_grad]
         self.last_stats: dict = {}
+        self.debug = False
+        self._launch_log: list[int] = []
+        self._debug_checks = 0
+
+    # same debug surface as the C++ reducer
+    def set_debug(self, on: bool) -> None:
+        self.debug = bool(on)
+
+    def set_roctx(self, on: bool) -> None:  # markers come from the C++ reducer only
+        pass
+
+    def launch_log(self) -> list[int]:
+        return list(self._launch_log)
+
+    def debug_checks(self) -> int:
+        return self._debug_checks
+
+    def close(self) -> None:
+        self.remove_hooks()
 
     # ------------------------------------------------------------- planning
     def _build(self, order: list[int]) -> None:
@@ -91,6 +110,7 @@ class PyReducer:
             b.handle = None
         self._next_bucket = 0
         self._callback_queued = False
+        self._launch_log = []
         if not self.rebuilt:
             self._ready_order = []
 
@@ -117,7 +137,14 @@ class PyReducer:
             self._launch(self.buckets[self._next_bucket])
             self._next_bucket += 1
 
-    def _launch(self, bk: _Bucket) -> None:
+    def _launch(self, bk: _Bucket, from_finalize: bool = False) -> None:
+        bidx = self.buckets.index(bk)
+        if self.debug:
+            assert bidx == len(self._launch_log), f"bucket {bidx} launched out of plan order"
+            assert not bk.launched, f"bucket {bidx} launched twice in one iteration"
+            assert from_finalize or (bk.pending == 0 and all(bk.ready)), f"bucket {bidx} launched with gradients missing"
+            self._debug_checks += 1
+        self._launch_log.append(bidx)
         grads, views = [], []
         for i, v in zip(bk.spec.param_indices, bk.views):
             g = self.params[i].grad
@@ -141,11 +168,14 @@ class PyReducer:
             return
         # parameters that never produced a gradient (unused in this graph) are zero-filled
         for bk in self.buckets[self._next_bucket:]:
-            self._launch(bk)
+            self._launch(bk, from_finalize=True)
         self._next_bucket = len(self.buckets)
         for bk in self.buckets:
             self.comm.wait(bk.handle)
             bk.handle = None
+        if self.debug:
+            assert all(bk.launched for bk in self.buckets) and len(self._launch_log) == len(self.buckets)
+            self._debug_checks += 1
         for bk in self.buckets:
             for i, v in zip(bk.spec.param_indices, bk.views):
                 p = self.params[i]

@@ -71,6 +71,10 @@ def enable_roctx(flag: bool = True) -> bool:
     return _ROCTX_ENABLED
 
 
+def roctx_enabled() -> bool:
+    return _ROCTX_ENABLED
+
+
 @contextlib.contextmanager
 def range_(name: str):
     """roctx range when enabled, otherwise free."""

@@ -25,8 +25,9 @@ def run(fn_name, rank, world, port, out_dir, kwargs):
         _init(rank, world, port)
         result = globals()[fn_name](rank, world, **kwargs)
         torch.save(result, os.path.join(out_dir, f"result_{rank}.pt"))
-        tdist.barrier()
-        tdist.destroy_process_group()
+        if tdist.is_initialized():
+            tdist.barrier()
+            tdist.destroy_process_group()
     except Exception:
         traceback.print_exc()
         with open(os.path.join(out_dir, f"error_{rank}.txt"), "w") as f:
@@ -203,3 +204,48 @@ def checkpoint_roundtrip(rank, world, path=None):
     got = [step(), step()]
     same = all(torch.allclose(p, after[n], atol=1e-6) for n, p in ddp2.module.named_parameters())
     return {"wrote": wrote, "meta": meta, "expect": expect, "got": got, "same": same}
+
+
+def reducer_debug_mode(rank, world, reducer="native", diverge=False):
+    """Debug mode: launch-order / readiness assertions run in every iteration, and the engine's replica
+    checksum catches a parameter that diverged on one rank."""
+    from pytorch_distributed_training_amd import nn as pnn
+    from pytorch_distributed_training_amd.parallel import DistributedDataParallel
+
+    net = pnn.convert_sync_batchnorm(_toy(seed=rank))
+    ddp = DistributedDataParallel(net, reducer=reducer, bucket_cap_mb=0.0005, first_bucket_mb=0.0005, check_replicas=True)
+    x, y = _data()
+    per = x.shape[0] // world
+    crit = pnn.CrossEntropyLoss()
+    logs = []
+    for _ in range(3):
+        for p in ddp.parameters():
+            p.grad = None
+        crit(ddp(x[rank * per:(rank + 1) * per]), y[rank * per:(rank + 1) * per]).backward()
+        logs.append(ddp.reducer.launch_log())
+    ddp.assert_replicas_equal()
+    caught = None
+    if diverge:
+        if rank == 1:
+            with torch.no_grad():
+                next(ddp.parameters()).view(-1)[0] += 1.0
+        try:
+            ddp.assert_replicas_equal()
+        except AssertionError as e:
+            caught = str(e)
+    nb = len(ddp.reducer.bucket_specs())
+    return {"logs": logs, "buckets": nb, "checks": ddp.reducer.debug_checks(), "caught": caught}
+
+
+def engine_shutdown(rank, world):
+    """``dist.shutdown(engine)``: ordered teardown at W=2 (gloo): returns, and the group is gone afterwards."""
+    from pytorch_distributed_training_amd import dist as pdist
+    from pytorch_distributed_training_amd.engine import Engine, EngineConfig
+
+    eng = Engine(EngineConfig(model="resnet18", num_classes=10, dtype="fp32", optimizer="sgd", lr=0.05, sync_bn=True,
+                              seed=0, check_replicas=True, check_replicas_every=2))
+    g = torch.Generator().manual_seed(rank)
+    x, y = torch.rand(4, 3, 16, 16, generator=g), torch.randint(0, 10, (4,), generator=g)
+    losses = [float(eng.train_step(x, y)) for _ in range(4)]
+    pdist.shutdown(eng, timeout_s=60)
+    return {"losses": losses, "initialized_after": tdist.is_initialized()}

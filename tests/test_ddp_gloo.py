@@ -216,3 +216,52 @@ def test_bucket_cap_autotune_agrees_across_ranks(free_port, tmp_path):
     assert picks[0] == picks[1] and picks[0] in (4.0, 8.0, 16.0, 32.0, 64.0)
     assert set(res[0]["tune"]["seconds_per_allreduce"]) == {"4", "8", "16", "32", "64"}
     assert res[0]["buckets"] == res[1]["buckets"]
+
+
+@pytest.mark.parametrize("reducer", REDUCERS)
+def test_reducer_debug_mode_and_replica_check(reducer, free_port, tmp_path):
+    """the debug assertions run (and pass) every iteration, buckets go out in plan order on both ranks,
+    and a parameter diverged on one rank is caught by the checksum all-gather on EVERY rank."""
+    res = spawn("reducer_debug_mode", 2, free_port, tmp_path, reducer=reducer, diverge=True)
+    for r in res:
+        assert r["buckets"] >= 3
+        assert all(log == list(range(len(log))) and len(log) >= 3 for log in r["logs"])
+        assert r["checks"] >= 3 * r["buckets"]
+        assert r["caught"] is not None and "replica divergence" in r["caught"]
+    assert res[0]["logs"][-1] == res[1]["logs"][-1]
+
+
+def test_ordered_shutdown_two_ranks(free_port, tmp_path):
+    res = spawn("engine_shutdown", 2, free_port, tmp_path)
+    assert all(not r["initialized_after"] for r in res)
+    assert all(l == l for r in res for l in r["losses"])
+
+
+def test_main_py_mid_epoch_resume_matches_uninterrupted_run(tmp_path, free_port, repo_root):
+    """--checkpoint_every saves a position INSIDE the epoch; --resume continues from it: same number of steps in
+    total, same final parameters as the run that was never interrupted."""
+    def run(extra, port, cwd):
+        os.makedirs(cwd, exist_ok=True)
+        cmd = [sys.executable, "-m", "pytorch_distributed_training_amd.launch", "--nproc_per_node=2",
+               f"--master_port={port}", os.path.join(repo_root, "main.py"), "--backend", "gloo", "--model", "resnet18",
+               "--dataset", "synthetic-cifar10", "--num_classes", "10", "--dataset_len", "64", "--batch_size", "4",
+               "--dtype", "fp32", "--profile", "none", "--epochs", "2", "--seed", "0", "--optimizer", "sgd",
+               "--no_graph"] + extra
+        env = dict(os.environ, PYTHONPATH=repo_root, OMP_NUM_THREADS="1")
+        r = subprocess.run(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:]
+        return r.stdout
+
+    full, part, resumed = str(tmp_path / "full.pt"), str(tmp_path / "part.pt"), str(tmp_path / "resumed.pt")
+    run(["--checkpoint", full], free_port, str(tmp_path / "a"))          # 2 epochs x 8 steps, uninterrupted
+    run(["--checkpoint", part, "--checkpoint_every", "3", "--steps", "9"], free_port + 1, str(tmp_path / "b"))
+    st9 = torch.load(part, weights_only=True)
+    # step 9 = first batch of epoch 1: the checkpoint records the position inside the epoch
+    assert st9["global_step"] == 9 and st9["epoch"] == 1 and st9["extra"]["samples_in_epoch"] == 4
+    out = run(["--checkpoint", resumed, "--resume", part], free_port + 2, str(tmp_path / "c"))
+    assert "Epoch: 1 step: 0 " not in out  # the batch that was already trained is not replayed
+    a = torch.load(full, weights_only=True)
+    b = torch.load(resumed, weights_only=True)
+    assert a["global_step"] == b["global_step"] == 16 and a["epoch"] == b["epoch"] == 2
+    for k, v in a["model"].items():
+        assert torch.allclose(v.float(), b["model"][k].float(), atol=1e-5, rtol=1e-4), k

@@ -412,6 +412,47 @@ def test_reducer_runs_the_rccl_path_with_a_size1_communicator(tmp_path):
     assert 0.0 <= c["overlap_fraction"] <= 1.0 and c["allreduce_span_ms"] >= 0 and c["exposed_ms"] >= 0
 
 
+def test_hip_graph_with_rccl_allreduce_debug_and_shutdown(tmp_path):
+    """Multi-rank hipGraph rehearsal on one GPU: with a size-1 communicator (PDT_FORCE_COMM=1) the captured step
+    contains the flatten -> fence -> ncclAllReduce on the communicator's stream -> event join, and its replays must
+    give the eager losses bit for bit.  Runs with the reducer's debug assertions and roctx ranges on, and ends with
+    the ordered teardown (watchdog join -> stream drain -> ncclCommDestroy -> c10d)."""
+    code = (
+        "import os, sys, json, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from pytorch_distributed_training_amd import dist as pdist\n"
+        "from pytorch_distributed_training_amd.utils import profiling\n"
+        "from pytorch_distributed_training_amd.engine import Engine, EngineConfig\n"
+        "pdist.init_process_group(backend='rccl', local_rank=0)\n"
+        "profiling.enable_roctx(True)\n"
+        "use_graph = os.environ['USE_GRAPH'] == '1'\n"
+        "eng = Engine(EngineConfig(model='resnet18', num_classes=10, dtype='bf16', optimizer='sgd', lr=0.05, seed=0,\n"
+        "                          graph=use_graph, check_replicas=True, check_replicas_every=3))\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "x = torch.rand(32, 3, 32, 32, generator=g).cuda(); y = torch.randint(0, 10, (32,), generator=g).cuda()\n"
+        "losses = [float(eng.train_step(x, y)) for _ in range(9)]\n"
+        "out = {'losses': losses, 'rccl': eng.net.reducer.rccl is not None, 'graph': eng._graph is not None,\n"
+        "       'failed': eng._graph_failed, 'checks': eng.net.reducer.debug_checks(), 'log': eng.net.reducer.launch_log(),\n"
+        "       'nb': len(eng.net.reducer.bucket_tensors())}\n"
+        "comm = eng.net.reducer.rccl\n"
+        "pdist.shutdown(eng)\n"
+        "out['closed'] = bool(comm.closed); out['init_after'] = pdist.is_initialized()\n"
+        "print(json.dumps(out))\n"
+    ) % ROOT
+    outs = []
+    for use_graph in ("0", "1"):
+        env = dict(os.environ, PDT_FORCE_COMM="1", USE_GRAPH=use_graph, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553",
+                   RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=tmp_path)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    eager, graph = outs
+    assert eager["rccl"] and graph["rccl"] and graph["graph"], graph
+    assert eager["losses"] == graph["losses"], (eager["losses"], graph["losses"])
+    assert eager["checks"] > 0 and eager["log"] == list(range(eager["nb"]))
+    assert eager["closed"] and graph["closed"] and not eager["init_after"] and not graph["init_after"]
+
+
 def test_ipc_small_allreduce_two_processes_on_one_gpu(tmp_path):
     """SURVEY 5.8 layer 3 / 2.5 S4: the one-kernel all-reduce over IPC-mapped mailboxes, with two processes that
     share GPU 0 (the only multi-process GPU set-up a one-GPU box allows; the peers' stores then stay on the device
