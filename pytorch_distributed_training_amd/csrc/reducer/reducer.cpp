@@ -111,6 +111,7 @@ Reducer::~Reducer() {
 }
 
 void Reducer::remove_hooks() {
+    std::lock_guard<std::mutex> g(mu_);
     for (size_t k = 0; k < accumulators_.size(); ++k) accumulators_[k]->del_post_hook(hook_keys_[k]);
     accumulators_.clear();
     hook_keys_.clear();
@@ -398,16 +399,19 @@ std::tuple<std::vector<double>, double, double> Reducer::comm_stats() {
 }
 
 std::vector<std::vector<int64_t>> Reducer::bucket_indices() const {
+    std::lock_guard<std::mutex> g(mu_);
     std::vector<std::vector<int64_t>> out;
     for (const auto& b : buckets_) out.push_back(b.plan.params);
     return out;
 }
 std::vector<int64_t> Reducer::bucket_numels() const {
+    std::lock_guard<std::mutex> g(mu_);
     std::vector<int64_t> out;
     for (const auto& b : buckets_) out.push_back(b.plan.numel);
     return out;
 }
 std::vector<at::Tensor> Reducer::bucket_tensors() const {
+    std::lock_guard<std::mutex> g(mu_);
     std::vector<at::Tensor> out;
     for (const auto& b : buckets_) out.push_back(b.flat);
     return out;

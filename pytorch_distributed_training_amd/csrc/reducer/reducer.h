@@ -38,11 +38,13 @@ class Reducer {
     ~Reducer();
 
     void prepare_for_backward();
-    void set_require_sync(bool v) { require_sync_ = v; }
-    bool rebuilt() const { return rebuilt_; }
-    int64_t iteration() const { return iteration_; }
-    std::vector<int64_t> ready_order() const { return ready_order_; }
-    std::vector<int64_t> current_order() const { return order_; }
+    void set_require_sync(bool v) { std::lock_guard<std::mutex> g(mu_); require_sync_ = v; }
+    // (every getter takes the mutex: the autograd thread appends to these vectors while hooks fire; found by the
+    // AddressSanitizer build of csrc/tests/reducer_sanitize_test.cpp, which polls them from a second thread)
+    bool rebuilt() const { std::lock_guard<std::mutex> g(mu_); return rebuilt_; }
+    int64_t iteration() const { std::lock_guard<std::mutex> g(mu_); return iteration_; }
+    std::vector<int64_t> ready_order() const { std::lock_guard<std::mutex> g(mu_); return ready_order_; }
+    std::vector<int64_t> current_order() const { std::lock_guard<std::mutex> g(mu_); return order_; }
     void rebuild(const std::vector<int64_t>& order);  // call between iterations
     std::vector<std::vector<int64_t>> bucket_indices() const;
     std::vector<int64_t> bucket_numels() const;
@@ -63,9 +65,9 @@ class Reducer {
     // recorded this iteration and has really completed once the compute stream has waited for it.  Also keeps
     // the launch sequence of the last iteration for tests.  Costs one stream synchronisation per step.
     void set_debug(bool on);
-    bool debug() const { return debug_; }
-    std::vector<int64_t> launch_log() const { return launch_log_; }
-    int64_t debug_checks() const { return debug_checks_; }
+    bool debug() const { std::lock_guard<std::mutex> g(mu_); return debug_; }
+    std::vector<int64_t> launch_log() const { std::lock_guard<std::mutex> g(mu_); return launch_log_; }
+    int64_t debug_checks() const { std::lock_guard<std::mutex> g(mu_); return debug_checks_; }
     // roctx range (rocprofv3 --marker-trace) around every bucket's flatten + all-reduce enqueue and around finalize
     void set_roctx(bool on);
 
@@ -113,7 +115,7 @@ class Reducer {
     std::vector<std::pair<size_t, size_t>> where_;  // param -> (bucket, slot)
     std::vector<std::shared_ptr<torch::autograd::Node>> accumulators_;
     std::vector<uintptr_t> hook_keys_;
-    std::mutex mu_;
+    mutable std::mutex mu_;
 };
 
 }  // namespace pdt
