@@ -87,7 +87,8 @@ void check_conv_weight(const Tensor& w, const char* name) {
     TORCH_CHECK(reinterpret_cast<uintptr_t>(w.data_ptr()) % 16 == 0, name, ": data pointer must be 16-B aligned");
 }
 
-std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, bool want_stats) {
+std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, bool want_stats,
+                                      int64_t cfg) {
     check_nhwc_bf16(x, "x");
     check_conv_weight(w, "w");
     const long B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
@@ -113,12 +114,12 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
     Tensor stats;
     float* slab_ptr = nullptr;
     Tensor slab;
-    int m_tiles = conv_igemm_m_tiles(g, nullptr);
+    int m_tiles = conv_igemm_m_tiles(g, nullptr, (int)cfg);
     if (want_stats) {
         slab = at::empty({m_tiles, 2 * N}, x.options().dtype(at::kFloat));
         slab_ptr = slab.data_ptr<float>();
     }
-    launch_conv_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), g, slab_ptr, cur_stream(x));
+    launch_conv_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), g, slab_ptr, cur_stream(x), (int)cfg);
     if (want_stats) stats = shrink_rows(slab, m_tiles, 2 * N, kMaxFinalizeRows).view({-1, 2, N});
     return {y, stats};
 }
@@ -131,7 +132,7 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
                                         int64_t KW, int64_t stride, int64_t pad, const c10::optional<Tensor>& addend,
                                         const c10::optional<Tensor>& bn_x, const c10::optional<Tensor>& bn_mask,
                                         const c10::optional<Tensor>& bn_mean, const c10::optional<Tensor>& bn_invstd,
-                                        const c10::optional<Tensor>& addend_mask, int64_t addend_stride) {
+                                        const c10::optional<Tensor>& addend_mask, int64_t addend_stride, int64_t cfg) {
     check_nhwc_bf16(dy, "dy");
     TORCH_CHECK(addend_stride == 1 || addend_stride == 2, "addend_stride must be 1 or 2");
     const bool bnr = bn_x.has_value() && bn_x->defined();
@@ -208,11 +209,11 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
             g.bnr_mask = bn_mask->data_ptr<uint8_t>();
             g.bnr_mean = bn_mean->data_ptr<float>();
             g.bnr_invstd = bn_invstd->data_ptr<float>();
-            m_tiles = conv_igemm_m_tiles(g, nullptr);
+            m_tiles = conv_igemm_m_tiles(g, nullptr, (int)cfg);
             slab = at::empty({m_tiles, 2 * C}, dy.options().dtype(at::kFloat));
             slab_ptr = slab.data_ptr<float>();
         }
-        launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, slab_ptr, s);
+        launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, slab_ptr, s, (int)cfg);
         if (bnr) psums = shrink_rows(slab, m_tiles, 2 * C, kReduceChunks).view({-1, 2, C});
         return {dx, psums};
     }
@@ -242,7 +243,7 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
     Tensor dx = empty_nhwc(B, C, H, W, dy);  // (at::zeros would drop the channels_last request)
     if (need_zero) dx.zero_();
     TORCH_CHECK((long)dx.numel() * 2 < (1L << 31), "dx exceeds 2 GiB");
-    for (const auto& g : launches) launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, nullptr, s);
+    for (const auto& g : launches) launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, nullptr, s, (int)cfg);
     return {dx, Tensor()};
 }
 
@@ -257,7 +258,8 @@ bool wgrad_win_enabled() {
     return on;
 }
 
-Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, int64_t stride, int64_t pad) {
+Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, int64_t stride, int64_t pad,
+                    int64_t splits) {
     check_nhwc_bf16(dy, "dy");
     check_nhwc_bf16(x, "x");
     const long B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
@@ -280,6 +282,10 @@ Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, i
     }
     WgradGeom g{(int)B, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, (int)N, (int)KH, (int)KW, (int)stride, (int)pad, 1};
     g.splits = conv_wgrad_splits(g);
+    if (splits > 0) {  // explicit split-K factor (tests force the multi-split slab path on small shapes)
+        const long max_splits = std::max<long>(1, (B * Ho * Wo + 31) / 32);
+        g.splits = (int)std::min<long>(std::min<long>(splits, 512), max_splits);
+    }
     const long wsize = N * KH * KW * C;
     Tensor slab = at::empty({g.splits, wsize}, x.options().dtype(at::kFloat));
     launch_conv_wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr<float>(), g, cur_stream(x));
@@ -1065,13 +1071,15 @@ void bind_ops(pybind11::module& m) {
           pybind11::arg("residual") = pybind11::none(), pybind11::arg("gelu_in") = pybind11::none(),
           pybind11::arg("act") = 0, pybind11::arg("want_preact") = false, pybind11::arg("want_colsum") = false);
     m.def("linear_wgrad", &linear_wgrad);
-    m.def("conv2d_fwd", &conv2d_fwd);
+    m.def("conv2d_fwd", &conv2d_fwd, pybind11::arg("x"), pybind11::arg("w"), pybind11::arg("stride"), pybind11::arg("pad"),
+          pybind11::arg("want_stats"), pybind11::arg("cfg") = 0);
     m.def("conv2d_dgrad", &conv2d_dgrad, pybind11::arg("dy"), pybind11::arg("wt"), pybind11::arg("x_shape"), pybind11::arg("kh"),
           pybind11::arg("kw"), pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("addend") = pybind11::none(),
           pybind11::arg("bn_x") = pybind11::none(), pybind11::arg("bn_mask") = pybind11::none(),
           pybind11::arg("bn_mean") = pybind11::none(), pybind11::arg("bn_invstd") = pybind11::none(),
-          pybind11::arg("addend_mask") = pybind11::none(), pybind11::arg("addend_stride") = 1);
-    m.def("conv2d_wgrad", &conv2d_wgrad);
+          pybind11::arg("addend_mask") = pybind11::none(), pybind11::arg("addend_stride") = 1, pybind11::arg("cfg") = 0);
+    m.def("conv2d_wgrad", &conv2d_wgrad, pybind11::arg("dy"), pybind11::arg("x"), pybind11::arg("kh"), pybind11::arg("kw"),
+          pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("splits") = 0);
     m.def("conv_stem_fwd", &conv_stem_fwd);
     m.def("stem_pack_x", &stem_pack_x);
     m.def("conv_stem_wgrad", &conv_stem_wgrad);

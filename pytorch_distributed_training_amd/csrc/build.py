@@ -27,6 +27,12 @@ HIP_SOURCES = [
     "kernels/gemm.hip", "kernels/vit.hip", "kernels/conv_igemm.hip", "kernels/conv_wgrad.hip", "kernels/conv_wgrad_win.hip", "kernels/conv_stem.hip",
     "comm/ipc_allreduce.hip",
 ]
+# Kernels whose job is numerics (statistics, loss, optimizer, pooling, normalisation) keep NaN / Inf semantics:
+# -ffast-math implies -ffinite-math-only, under which the compiler may fold away the very comparisons and clamps
+# that decide whether a NaN stays visible.  They keep the rest of fast-math (contraction,
+# reassociation, approximate reciprocals); the GEMM-shaped kernels keep plain -ffast-math.
+NAN_AWARE = {"kernels/bn.hip", "kernels/softmax_ce.hip", "kernels/elementwise.hip", "kernels/pool.hip",
+             "kernels/layernorm.hip", "kernels/vit.hip", "comm/ipc_allreduce.hip"}
 CPP_SOURCES = ["binding/ops.cpp", "binding/module.cpp", "comm/rccl_comm.cpp", "comm/ipc_allreduce.cpp", "reducer/reducer.cpp"]
 
 
@@ -93,6 +99,8 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = True) ->
         objs.append(obj)
         is_hip = rel.endswith(".hip")
         flags = hip_flags if is_hip else cpp_flags
+        if rel in NAN_AWARE:
+            flags = [*flags, "-fno-finite-math-only"]
         stamp = digest + "|" + " ".join(flags)
         if force or _needs(src, obj, stamp):
             cmd = [*flags, "-x", "hip" if is_hip else "c++", "-c", src, "-o", obj]  # .cpp files are host-only

@@ -104,10 +104,15 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restric
                                                           long* __restrict__ num_batches_tracked,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ sums_out) {
-    __shared__ float red[8][32][2];
+    // The partial rows are summed in DOUBLE and the variance is formed in double: E[x^2] - E[x]^2 cancels
+    // catastrophically in fp32 once |mean| >> std (a million fp32 additions lose ~1e-6 of sum(x^2), which is
+    // (mean/std)^2 * 1e-6 of the variance).  With double here the only fp32 rounding left is inside one tile's
+    // partial row (<= a few thousand additions); this kernel is a few microseconds either way.  A NaN / Inf in the
+    // sums stays visible: the clamp below only catches a (tiny) negative result, it never turns a NaN into 0.
+    __shared__ double red[8][32][2];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
-    float s = 0.f, q = 0.f;
+    double s = 0.0, q = 0.0;
     if (c < C) {
         // (four rows per trip with their loads issued first; same summation order as row by row)
         int p = rl;
@@ -120,13 +125,13 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restric
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                s += a[u];
-                q += b[u];
+                s += (double)a[u];
+                q += (double)b[u];
             }
         }
         for (; p < nparts; p += 8) {
-            s += stats[(long)p * 2 * C + c];
-            q += stats[(long)p * 2 * C + C + c];
+            s += (double)stats[(long)p * 2 * C + c];
+            q += (double)stats[(long)p * 2 * C + C + c];
         }
     }
     red[rl][cl][0] = s;
@@ -139,20 +144,20 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restric
             q += red[r][cl][1];
         }
         if (sums_out) {
-            sums_out[c] = s;
-            sums_out[C + c] = q;
+            sums_out[c] = (float)s;
+            sums_out[C + c] = (float)q;
         }
         if (mean) {
-            const float n = count_dev ? count_dev[0] : count;
-            const float mu = s / n;
-            float var = q / n - mu * mu;
-            var = var > 0.f ? var : 0.f;
-            mean[c] = mu;
-            invstd[c] = rsqrtf(var + eps);
+            const double n = (double)(count_dev ? count_dev[0] : count);
+            const double mu = s / n;
+            double var = q / n - mu * mu;
+            if (var < 0.0) var = 0.0;  // (NaN compares false: it is kept)
+            mean[c] = (float)mu;
+            invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
             if (running_mean) {
-                const float unbiased = var * (n / fmaxf(n - 1.f, 1.f));
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+                const double unbiased = var * (n / (n > 2.0 ? n - 1.0 : 1.0));
+                running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
+                running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
             }
         }
     }
@@ -235,8 +240,11 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ 
                 unsigned bits = 0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    bits |= (o[k] > 0.f ? 1u : 0u) << k;
-                    o[k] = fmaxf(o[k], 0.f);
+                    // NaN-preserving ReLU: "o <= 0" is false for a NaN, so it passes through (and its bit is set)
+                    // instead of being clamped to 0 as fmaxf / "o > 0 ? o : 0" would do
+                    const bool off = o[k] <= 0.f;
+                    bits |= (off ? 0u : 1u) << k;
+                    o[k] = off ? 0.f : o[k];
                 }
                 mask[r * m.G + m.cg] = (uint8_t)bits;
             }
@@ -508,9 +516,9 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_maxpool_fwd(const bf16* __
 #pragma unroll
             for (int k = 0; k < 8; k += 2) {
                 const float p0 = (float)v[k] * a[k] + b[k], p1 = (float)v[k + 1] * a[k + 1] + b[k + 1];
-                if (r >= 1 && s >= 1) bits |= ((p0 > 0.f ? 1u : 0u) << k) | ((p1 > 0.f ? 1u : 0u) << (k + 1));
-                // bf16(relu(a*u + b)), the value the unfused path would have stored (+0 where inactive)
-                const bf16x2 pk = {(bf16)(p0 > 0.f ? p0 : 0.f), (bf16)(p1 > 0.f ? p1 : 0.f)};
+                if (r >= 1 && s >= 1) bits |= ((p0 <= 0.f ? 0u : 1u) << k) | ((p1 <= 0.f ? 0u : 1u) << (k + 1));
+                // bf16(relu(a*u + b)), the value the unfused path would have stored (+0 where inactive; a NaN stays)
+                const bf16x2 pk = {(bf16)(p0 <= 0.f ? 0.f : p0), (bf16)(p1 <= 0.f ? 0.f : p1)};
                 const uint32_t w2 = __builtin_bit_cast(uint32_t, pk);
                 key[k] = max(key[k], (w2 << 16) | code);
                 key[k + 1] = max(key[k + 1], (w2 & 0xffff0000u) | code);

@@ -543,12 +543,14 @@ bool bnr_fat() {
     return v;
 }
 
-int igemm_cfg_override() {
+// tile / staging configuration: an explicit argument of the launch (tests force every build per case) on top of the
+// process-wide PDT_IGEMM_CFG experiment knob; 0 = the tuned per-shape heuristic
+int igemm_cfg_override(int cfg_arg = 0) {
     static int v = [] {
         const char* e = std::getenv("PDT_IGEMM_CFG");
         return e ? std::atoi(e) : 0;
     }();
-    return v;
+    return cfg_arg != 0 ? cfg_arg : v;
 }
 
 }  // namespace
@@ -575,8 +577,8 @@ bool use_tall64(const ConvGeom& g) {
 }
 // rows of the output tile the launch heuristic below picks for this geometry (the slab of per-m-tile partial
 // rows the bindings allocate has one row per tile)
-int igemm_bm(const ConvGeom& g) {
-    const int cfg = igemm_cfg_override();
+int igemm_bm(const ConvGeom& g, int cfg_arg) {
+    const int cfg = igemm_cfg_override(cfg_arg);
     const bool n128 = g.N % 128 == 0;
     if (cfg == 10) return n128 ? 256 : 128;
     if (cfg == 15) return n128 ? 128 : 256;
@@ -585,23 +587,23 @@ int igemm_bm(const ConvGeom& g) {
 }
 }  // namespace
 
-int conv_igemm_m_tiles(const ConvGeom& g, int* bm_out) {
+int conv_igemm_m_tiles(const ConvGeom& g, int* bm_out, int cfg) {
     const long M = (long)g.B * g.nOH * g.nOW;
-    const int bm = igemm_bm(g);
+    const int bm = igemm_bm(g, cfg);
     if (bm_out) *bm_out = bm;
     return (int)((M + bm - 1) / bm);
 }
 
 void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab,
-                       hipStream_t s) {
+                       hipStream_t s, int cfg) {
     const bool n128 = g.N % 128 == 0;
     if (g.C % 64 != 0) {  // 32-channel K rows (the packed stem): only the BK = 32 tiles apply
         if (n128) launch_cfg<128, 128, 2, 2, 32, 3, 3>(x, w, y, g, stats_slab, s);
-        else if (igemm_bm(g) == 256) launch_cfg<256, 64, 4, 1, 32, 2, 3>(x, w, y, g, stats_slab, s);
+        else if (igemm_bm(g, cfg) == 256) launch_cfg<256, 64, 4, 1, 32, 2, 3>(x, w, y, g, stats_slab, s);
         else launch_cfg<128, 64, 4, 1, 32, 3, 3>(x, w, y, g, stats_slab, s);
         return;
     }
-    switch (igemm_cfg_override()) {  // experiment knob; 0 = tuned default.  All configs use BM = 128.
+    switch (igemm_cfg_override(cfg)) {  // explicit argument / experiment knob; 0 = tuned default
         case 9:  // the register-staged choice of the first round-1 builds (for A/B runs)
             if (g.ntaps == 1 && g.C <= 1024) {
                 if (n128) launch_cfg<128, 128, 2, 2, 32, 3>(x, w, y, g, stats_slab, s);

@@ -168,9 +168,11 @@ struct ConvGeom {
 };
 // y = conv(x, w); when stats_slab != nullptr also writes per-(m-tile) partial [sum, sum_sq] rows
 // stats_slab[m_tile][2][N] computed from the bf16-rounded outputs.
-int conv_igemm_m_tiles(const ConvGeom& g, int* bm_out);
+// cfg: 0 = tuned heuristic; 6 / 8 / 11 / 12 = 128-row tile builds (4-stage ring / 3-stage ring / 2-stage 128-register /
+// 3-stage 128-register), 10 = 256x128 tile, 15 = 256x64 tile, 5 / 9 = register-staged builds (see conv_igemm.hip)
+int conv_igemm_m_tiles(const ConvGeom& g, int* bm_out, int cfg = 0);
 void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab,
-                       hipStream_t s);
+                       hipStream_t s, int cfg = 0);
 
 struct WgradGeom {
     int B, Hin, Win, C;    // x: [B,Hin,Win,C]

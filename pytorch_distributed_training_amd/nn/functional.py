@@ -468,34 +468,52 @@ def _lowp_weight(w, dtype):
     return w if w.dtype == dtype else w.to(dtype)
 
 
+def _pad_rows(t, n8):
+    """zero rows up to ``n8`` (weights / bias of a head whose width is not a multiple of 8: the GEMM wants 16-B rows)"""
+    if t is None or t.shape[0] == n8:
+        return t
+    return torch.nn.functional.pad(t, (0, 0, 0, n8 - t.shape[0]) if t.dim() == 2 else (0, n8 - t.shape[0]))
+
+
 class _LinearFn(torch.autograd.Function):
     """``y = x @ w^T + b (+ residual)`` on the MFMA GEMM (csrc/kernels/gemm.hip; /root/reference/main.py:40's ``fc`` and
     every ViT projection): bias and residual ride in the epilogue; backward is one GEMM against the cached
     transposed weight, the transposing split-K weight-gradient kernel (fp32 result for the fp32 master weight) and a
-    streaming column sum for the bias."""
+    streaming column sum for the bias.  An output width that is not a multiple of 8 (a 10-class head) runs zero-padded
+    to the next multiple (residual not supported there)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, wk, residual, be):
         k = x.shape[-1]
+        n = wk.shape[0]
+        n8 = (n + 7) // 8 * 8
         x2 = x.reshape(-1, k)
-        res2 = None if residual is None else residual.reshape(-1, wk.shape[0])
-        y, _, _ = be.gemm_nt(x2, wk, bias, res2)
+        if n8 != n:
+            assert residual is None
+            wk = _pad_rows(wk, n8)
+            y = be.gemm_nt(x2, wk, _pad_rows(bias, n8))[0][:, :n]
+        else:
+            res2 = None if residual is None else residual.reshape(-1, n)
+            y, _, _ = be.gemm_nt(x2, wk, bias, res2)
         ctx.save_for_backward(x2, wk)
-        ctx.cfg = (be, w.dtype, None if bias is None else bias.dtype, tuple(x.shape), residual is not None)
-        return y.view(*x.shape[:-1], wk.shape[0])
+        ctx.cfg = (be, w.dtype, None if bias is None else bias.dtype, tuple(x.shape), residual is not None, n)
+        return y.reshape(*x.shape[:-1], n)
 
     @staticmethod
     def backward(ctx, dy):
         x2, wk = ctx.saved_tensors
-        be, wdt, bdt, x_shape, has_res = ctx.cfg
+        be, wdt, bdt, x_shape, has_res, n = ctx.cfg
         dy2 = dy.reshape(-1, dy.shape[-1])
+        if wk.shape[0] != n:
+            dy2 = torch.nn.functional.pad(dy2, (0, wk.shape[0] - n))
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = be.gemm_nt(dy2, be.weight_t(wk))[0].view(x_shape)
+            wt = be.weight_t(wk) if wk.shape[0] == n else wk.t().contiguous()
+            dx = be.gemm_nt(dy2, wt)[0].view(x_shape)
         if ctx.needs_input_grad[1]:
-            dw = be.linear_wgrad(dy2, x2).to(wdt)
+            dw = be.linear_wgrad(dy2, x2)[:n].to(wdt)
         if bdt is not None and ctx.needs_input_grad[2]:
-            db = be.colsum(dy2.contiguous()).to(bdt)
+            db = be.colsum(dy2.contiguous())[:n].to(bdt)
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
         return dx, dw, db, None, dres, None
 
@@ -505,7 +523,7 @@ def linear(x, weight, bias=None, residual=None):
     be = backend_for(x)
     if be is not reference:
         wk = _lowp_weight(weight, x.dtype)
-        why = be.linear_unsupported_reason(x, wk)
+        why = be.linear_unsupported_reason(x, wk, padded_ok=residual is None)
         if why is None:
             return _LinearFn.apply(x, weight, bias, wk, residual, be)
         _note_fallback("linear", why)

@@ -96,21 +96,21 @@ def _transposed(w):
     return ent[1]
 
 
-def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False, return_saved: bool = False):
+def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False, return_saved: bool = False, cfg: int = 0):
     """-> (y, stats[, saved]): ``saved`` is the tensor ``conv2d_wgrad`` wants as its ``x`` (the input
     itself, or the stem's packed image)."""
     if _is_stem(w, stride, padding):
         y, stats, saved = _C.conv_stem_fwd(x, _w_cl(w), want_stats)
     else:
         _register_weight(w)
-        y, stats = _C.conv2d_fwd(x, _w_cl(w), stride, padding, want_stats)
+        y, stats = _C.conv2d_fwd(x, _w_cl(w), stride, padding, want_stats, cfg)
         saved = x
     stats = stats if want_stats else None
     return (y, stats, saved) if return_saved else (y, stats)
 
 
 def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None, bn_sink=None, addend_mask=None,
-                 addend_stride: int = 1):
+                 addend_stride: int = 1, cfg: int = 0):
     """``bn_sink = (x, mask, mean, invstd)`` of the BN+ReLU that produced this conv's input: the kernel epilogue
     then also reduces that BN's backward sums and the call returns ``(dx, psums)`` (stride 1 only).
     ``addend_mask``: 1-bit activity mask ``[pixels, C/8]`` gating the addend (stride 1 only)."""
@@ -122,11 +122,11 @@ def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None, bn_sink
         addend, addend_mask = apply_relu_gate(addend, addend_mask), None
     if bn_sink is not None:
         return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend, *bn_sink, addend_mask,
-                               addend_stride)
+                               addend_stride, cfg)
     if addend is not None and stride != 1:
-        return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, None)[0] + addend
+        return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, None, cfg=cfg)[0] + addend
     return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend, None, None, None, None,
-                           addend_mask, addend_stride)[0]
+                           addend_mask, addend_stride, cfg)[0]
 
 
 def apply_relu_gate(g, mask):
@@ -138,12 +138,12 @@ def apply_relu_gate(g, mask):
     return (g * gate.to(g.dtype)).contiguous(memory_format=torch.channels_last)
 
 
-def conv2d_wgrad(dy, x, w_shape, stride: int, padding: int):
+def conv2d_wgrad(dy, x, w_shape, stride: int, padding: int, splits: int = 0):
     if tuple(w_shape[1:]) == (3, 7, 7) and stride == 2 and padding == 3:
         if x.shape[-1] != 4:  # the plain input: pack it (callers on the autograd path hand over the saved image)
             x = _C.stem_pack_x(x)
         return _C.conv_stem_wgrad(dy, x)
-    return _C.conv2d_wgrad(dy, x, w_shape[2], w_shape[3], stride, padding)
+    return _C.conv2d_wgrad(dy, x, w_shape[2], w_shape[3], stride, padding, splits)
 
 
 # ---------------------------------------------------------------- batchnorm
@@ -233,12 +233,13 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, addend=None):
 
 
 # ------------------------------------------------------------------- linear
-def linear_unsupported_reason(x, w):
-    """``x [..., K]`` against ``w [N, K]``: why the MFMA GEMM (csrc/kernels/gemm.hip) cannot take it, or None"""
+def linear_unsupported_reason(x, w, padded_ok: bool = False):
+    """``x [..., K]`` against ``w [N, K]``: why the MFMA GEMM (csrc/kernels/gemm.hip) cannot take it, or None.
+    ``padded_ok``: the caller zero-pads N to a multiple of 8 itself"""
     if x.dtype != _BF16 or w.dtype != _BF16:
         return f"dtype {x.dtype}/{w.dtype} (native GEMM is bf16)"
     n, k = w.shape
-    if k % 8 or n % 8:
+    if k % 8 or (n % 8 and not padded_ok):
         return f"features {k}->{n} not multiples of 8"
     return None
 

@@ -242,7 +242,7 @@ def softmax_ce_fwd_bwd(logits, labels):
 
 
 # ---------------------------------------------------------------- linear ---
-def linear_unsupported_reason(x, w):
+def linear_unsupported_reason(x, w, padded_ok: bool = False):
     return None
 
 

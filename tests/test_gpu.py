@@ -61,6 +61,33 @@ def test_conv_kernels_fwd_dgrad_wgrad(kc, case):
     _assert_all_ok(kc, n)
 
 
+# Every implicit-GEMM build the headline benchmark runs at B = 1280, forced through the bindings' explicit ``cfg``
+# argument on shapes small enough for the test budget but with ragged M tails (M % 256 != 0) and several N tiles:
+# 10 = <256,128,32,2,3> (long-K / 256-channel 3x3), 15 = <256,64,32,2,3> (64-wide outputs), 6 = the 4-stage ring,
+# 11 = <128,128|64,32,4,2> (short-K, with the fused BN-reduce epilogue in dgrad_bnr), 12 / 8 = the 3-stage rings.
+@pytest.mark.parametrize("cfg,case", [
+    (10, (3, 256, 15, 15, 256, 3, 1, 1)), (10, (5, 1024, 9, 9, 256, 1, 1, 0)), (10, (2, 128, 29, 29, 384, 3, 2, 1)),
+    (15, (3, 64, 30, 30, 64, 3, 1, 1)), (15, (5, 256, 23, 23, 64, 1, 1, 0)), (15, (2, 128, 17, 17, 192, 3, 1, 1)),
+    (6, (3, 256, 15, 15, 256, 3, 1, 1)), (6, (2, 512, 7, 7, 512, 3, 1, 1)), (6, (2, 320, 11, 11, 64, 3, 2, 1)),
+    (11, (5, 64, 23, 23, 256, 1, 1, 0)), (11, (5, 256, 19, 19, 64, 1, 1, 0)), (11, (3, 128, 21, 21, 512, 1, 1, 0)),
+    (11, (3, 128, 20, 20, 128, 3, 2, 1)), (12, (3, 64, 30, 30, 64, 3, 1, 1)), (8, (3, 128, 21, 21, 128, 3, 1, 1)),
+    (8, (2, 512, 13, 13, 1024, 1, 2, 0))])
+def test_conv_every_igemm_build_forced(kc, cfg, case):
+    n = len(kc.RESULTS)
+    kc.check_conv(case, False, cfg=cfg)
+    _assert_all_ok(kc, n)
+
+
+@pytest.mark.parametrize("case,splits", [
+    ((3, 128, 21, 21, 128, 3, 1, 1), 7), ((5, 256, 9, 9, 1024, 1, 1, 0), 5), ((2, 64, 30, 30, 64, 3, 1, 1), 13),
+    ((3, 64, 23, 23, 128, 1, 1, 0), 9), ((3, 128, 20, 20, 64, 3, 2, 1), 4), ((2, 512, 7, 7, 512, 3, 1, 1), 3)])
+def test_conv_wgrad_every_tile_with_split_k(kc, case, splits):
+    """k_conv_wgrad<128,128>, <128,64>, <64,128>, <64,64> with several splits (ragged last split) + the slab reduce"""
+    n = len(kc.RESULTS)
+    kc.check_conv(case, False, splits=splits)
+    _assert_all_ok(kc, n)
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 1), (3, 197, 2), (2, 50, 3), (1, 256, 2), (2, 17, 1), (8, 197, 12)])
 def test_attention_kernels(kc, shape):
     n = len(kc.RESULTS)
@@ -258,13 +285,16 @@ def test_resnet50_bf16_step_loss_decreases_on_fixed_batch():
     assert not any(k.startswith("conv2d") for k in pF.fallback_counts), dict(pF.fallback_counts)  # stem included
 
 
-@pytest.mark.parametrize("model", ["resnet18", "resnet50"])
-def test_bf16_native_matches_oracles(model):
-    """Same weights, same batch, three ways: (A) stock fp32 ops, (B) stock ops on bf16 tensors
-    (MIOpen conv + ATen-style BN with the same rounding points), (C) the native HIP path.
-    bf16 through a deep randomly-initialised BN network is noisy by itself, so the criterion is:
-    C is as close to the fp32 oracle as the library bf16 path B is, for logits, loss and EVERY
-    parameter gradient."""
+@pytest.mark.parametrize("model,img,damp", [("resnet18", 64, 0.25), ("resnet50", 96, 0.1)])
+def test_bf16_native_matches_oracles(model, img, damp):
+    """The native bf16 HIP path against an fp32 run of the PyTorch oracles on the SAME bf16-rounded weights and
+    inputs (so the only difference is where activations are rounded and how sums are ordered), and against the
+    stock library ops on bf16 tensors.  EVERY parameter gradient is checked, none is skipped.
+
+    The residual branches are damped (last BN weight of every block = ``damp``, the non-zero cousin of
+    zero_init_residual): an undamped randomly initialised 50-layer BN network amplifies bf16 rounding chaotically
+    (library bf16 and native both end 35 %% away from fp32 in the logits), which measures the network, not the
+    kernels.  Measured with these settings: worst gradient cosine 0.94 (resnet50) / 0.93 (resnet18)."""
     from pytorch_distributed_training_amd import nn as pnn
     from pytorch_distributed_training_amd import ops
     from pytorch_distributed_training_amd.models import build_model
@@ -272,7 +302,14 @@ def test_bf16_native_matches_oracles(model):
 
     torch.manual_seed(0)
     net = build_model(model, num_classes=10).cuda()
-    x = torch.randn(32, 3, 64, 64, device="cuda")
+    last_bn = "bn2.weight" if model in ("resnet18", "resnet34") else "bn3.weight"
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith(last_bn):
+                p.fill_(damp)
+        for p in net.parameters():
+            p.copy_(p.to(torch.bfloat16).float())  # the fp32 oracle runs on exactly the weights the bf16 path sees
+    x = torch.randn(32, 3, img, img, device="cuda").to(torch.bfloat16)
     y = torch.randint(0, 10, (32,), device="cuda")
     crit = pnn.CrossEntropyLoss()
 
@@ -289,12 +326,12 @@ def test_bf16_native_matches_oracles(model):
             loss.backward()
         finally:
             ops.set_force_reference(False)
-        return out.detach().float(), float(loss), {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
+        return out.detach().float(), float(loss.detach()), {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
 
-    out_a, loss_a, g_a = run(x, True)
+    out_a, loss_a, g_a = run(x.float(), True)
     arena = ParamArena(net)
     arena.attach_lowp(torch.bfloat16)
-    xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xb = x.contiguous(memory_format=torch.channels_last)
     out_b, loss_b, g_b = run(xb, True)
     out_c, loss_c, g_c = run(xb, False)
 
@@ -307,16 +344,67 @@ def test_bf16_native_matches_oracles(model):
 
     eb, ec = rel(out_b, out_a), rel(out_c, out_a)
     print(f"{model}: logits err vs fp32: library-bf16 {eb:.4f}, native {ec:.4f}; native vs library {rel(out_c, out_b):.4f}")
-    assert ec < 1.5 * eb + 2e-2
-    assert abs(loss_c - loss_a) < 1.5 * abs(loss_b - loss_a) + 3e-2
+    assert ec < 5e-2 and ec < 1.5 * eb + 1e-2
+    assert abs(loss_c - loss_a) < 2e-2
     worst_b = worst_c = 1.0
-    for n in g_a:
+    for n in g_a:  # no parameter is skipped
         cb, cc = cos(g_b[n], g_a[n]), cos(g_c[n], g_a[n])
         worst_b, worst_c = min(worst_b, cb), min(worst_c, cc)
-        if cb > 0.9:  # where bf16 itself is chaotic (deep net, tiny images, random init) nothing can be said
-            assert cc > cb - 0.08, (n, cb, cc)
-            assert 0.7 < float(g_c[n].norm() / (g_a[n].norm() + 1e-12)) < 1.4, n
+        assert cc > 0.9, (n, cb, cc)
+        assert cc > cb - 0.05, (n, cb, cc)
+        assert 0.85 < float(g_c[n].norm() / (g_a[n].norm() + 1e-12)) < 1.2, n
     print(f"{model}: worst gradient cosine vs fp32: library-bf16 {worst_b:.4f}, native {worst_c:.4f}")
+
+
+def test_nan_in_the_input_reaches_loss_and_weights():
+    """a NaN must stay visible.  One NaN pixel in the batch -> NaN conv output -> NaN BatchNorm
+    statistics -> (NaN-preserving ReLU) -> NaN loss -> NaN weights after the optimizer step, for both fused
+    optimizers.  (-ffast-math would allow the compiler to assume this never happens: the numerics kernels are
+    built with -fno-finite-math-only, and the ReLU is written as "x <= 0 ? 0 : x".)"""
+    for opt in ("sgd", "adam"):
+        eng = _engine(model="resnet18", num_classes=10, optimizer=opt, lr=0.01, sync_bn=False)
+        g = torch.Generator().manual_seed(0)
+        x = torch.rand(8, 3, 32, 32, generator=g).cuda()
+        y = torch.randint(0, 10, (8,), generator=g).cuda()
+        assert float(eng.train_step(x, y)) == float(eng.train_step(x, y)) or True  # two clean steps first
+        before = [p.detach().clone() for p in eng.net.parameters()]
+        assert all(torch.isfinite(p).all() for p in before)
+        x[3, 1, 7, 9] = float("nan")
+        loss = eng.train_step(x, y)
+        assert torch.isnan(loss).item(), float(loss)
+        params = dict(eng.net.module.named_parameters())
+        assert torch.isnan(params["conv1.weight"]).any() and torch.isnan(params["fc.weight"]).any()
+        assert torch.isnan(params["layer1.0.bn1.weight"]).any()
+        lp = getattr(params["conv1.weight"], "_lp", None)
+        assert lp is None or torch.isnan(lp.float()).any()  # the bf16 working copy carries it too
+
+
+@pytest.mark.parametrize("shape", [(16, 64, 14, 14), (4, 256, 28, 28)])
+def test_batchnorm_statistics_with_mean_100_std(shape):
+    """|mean| = 100 * std: E[x^2] - E[x]^2 in fp32 over the whole tensor loses the variance; the finalize kernel
+    sums the per-tile partial rows and forms the variance in double.  Compared with the fp32/fp64 oracle on the same
+    bf16 tensor (torch's Welford-based batch_norm is the reference behaviour, /root/reference/main.py:82)."""
+    from pytorch_distributed_training_amd.ops import native
+
+    B, C, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(1)
+    std = torch.rand(C, device="cuda", generator=g) + 0.5
+    x = (torch.randn(B, C, H, W, device="cuda", generator=g) * std.view(1, C, 1, 1) + 100.0 * std.view(1, C, 1, 1))
+    x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xd = x.double()
+    mean_ref = xd.mean((0, 2, 3))
+    var_ref = xd.var((0, 2, 3), unbiased=False)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    mean, invstd = native.bn_finalize(native.bn_stats(x), float(B * H * W), 1e-5, rm, rv, 0.1, None)
+    assert ((mean.double() - mean_ref).abs() / mean_ref.abs()).max() < 1e-6
+    inv_ref = 1.0 / torch.sqrt(var_ref + 1e-5)
+    assert ((invstd.double() - inv_ref).abs() / inv_ref).max() < 2e-2, ((invstd.double() - inv_ref).abs() / inv_ref).max()
+    # the same through the conv epilogue's per-tile statistics (identity 1x1 convolution)
+    w = torch.eye(C, device="cuda").view(C, C, 1, 1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y, st = native.conv2d_fwd(x, w, 1, 0, True)
+    assert torch.equal(y, x)
+    mean2, invstd2 = native.bn_finalize(st, float(B * H * W), 1e-5)
+    assert ((invstd2.double() - inv_ref).abs() / inv_ref).max() < 2e-2
 
 
 def test_dataflow_fusions_do_not_change_the_native_result(monkeypatch):
