@@ -100,6 +100,9 @@ def conv_cases(quick):
     return cases
 
 
+GEMM_CORE = 100  # cfg: the GEMM core (csrc/kernels/gemm.hip) instead of an implicit-GEMM build
+
+
 def check_conv(args, time_it, cfg=0, splits=0):
     """``cfg``: force one implicit-GEMM build (csrc/kernels/kernels.h), ``splits``: force the weight gradient's split-K"""
     B, C, H, W, N, k, s, p = args
@@ -176,14 +179,20 @@ def check_conv(args, time_it, cfg=0, splits=0):
         # gated addend (lazily masked residual gradient): same as adding the materialised masked tensor
         gate_src = nhwc(B, C, H, W)
         _, gmask = native.bn_apply_act(gate_src, mean * 0, invstd * 0 + 1, gamma * 0 + 1, beta * 0, None, True)
-        dx3 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add, addend_mask=gmask)
-        dx4 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, native.apply_relu_gate(add, gmask))
-        dx5, ps5 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add, (xb, act, mean, invstd), gmask)
+        dx3 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add, addend_mask=gmask, cfg=cfg)
+        dx4 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, native.apply_relu_gate(add, gmask), cfg=cfg)
+        dx5, ps5 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add, (xb, act, mean, invstd), gmask, cfg=cfg)
         ps6 = native.bn_bwd_reduce(dx4, act, xb, mean, invstd, True)
         e2 = max(rel_err(dx3, dx4), rel_err(dx5, dx4),
                  rel_err(native.bn_sum_partials(ps5), native.bn_sum_partials(ps6)))
         ref_gate = (gate_src > 0)
         e2 = max(e2, rel_err(native.apply_relu_gate(add, gmask), add * ref_gate))
+        if cfg == GEMM_CORE:  # the same results from the implicit-GEMM kernel (bf16 roundings of identical sums)
+            dx0, ps0 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add, (xb, act, mean, invstd), gmask, cfg=6)
+            e2 = max(e2, rel_err(dx5, dx0), rel_err(native.bn_sum_partials(ps5), native.bn_sum_partials(ps0)))
+            dxb, psb = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, None, (xb, act, mean, invstd), cfg=cfg)
+            dxc, psc = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, None, (xb, act, mean, invstd), cfg=6)
+            e2 = max(e2, rel_err(dxb, dxc), rel_err(native.bn_sum_partials(psb), native.bn_sum_partials(psc)))
         record(f"conv_dgrad+gated_addend {tag}", e2 < 2e-3, e2, {})
         # compact stride-2 addend (gradient of a 1x1 stride-2 conv of the same input) == its zero-stuffed form
         if H % 2 == 0 and W % 2 == 0:

@@ -87,6 +87,26 @@ void check_conv_weight(const Tensor& w, const char* name) {
     TORCH_CHECK(reinterpret_cast<uintptr_t>(w.data_ptr()) % 16 == 0, name, ": data pointer must be 16-B aligned");
 }
 
+// cfg selecting the GEMM core (gemm.hip) instead of an implicit-GEMM build; 0 = pick by shape
+constexpr int64_t kCfgGemmCore = 100;
+
+// A pointwise stride-1 convolution in NHWC is C[M,N] = A[M,K] . W[N,K]^T with dense rows.  Measured at B=1024 on
+// every pointwise shape of ResNet-50 (bench/micro/gemm_conv_shapes.py): with Cout a multiple of the 256-column
+// tile the GEMM core is 0-35 % faster than the implicit-GEMM kernel (64->256 @56: 388 vs 572 us with the
+// statistics epilogue), with 64 / 128 output channels it loses (half-empty tiles).  PDT_CONV_GEMM=0 turns it off.
+bool conv_gemm_core_ok(long C, long N, long KH, long KW, long stride, long pad, int64_t cfg) {
+    static const bool enabled = [] {
+        const char* e = std::getenv("PDT_CONV_GEMM");
+        return !(e && std::string(e) == "0");
+    }();
+    const bool eligible = KH == 1 && KW == 1 && stride == 1 && pad == 0 && C % 64 == 0 && N % 8 == 0;
+    if (cfg == kCfgGemmCore) {
+        TORCH_CHECK(eligible, "the GEMM core takes pointwise stride-1 convolutions with Cin % 64 == 0");
+        return true;
+    }
+    return cfg == 0 && enabled && eligible && N % 256 == 0;
+}
+
 std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, bool want_stats,
                                       int64_t cfg) {
     check_nhwc_bf16(x, "x");
@@ -100,6 +120,23 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
     TORCH_CHECK(Ho > 0 && Wo > 0, "empty output");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor y = empty_nhwc(B, N, Ho, Wo, x);
+    if (conv_gemm_core_ok(C, N, KH, KW, stride, pad, cfg)) {
+        GemmArgs ga;
+        std::memset(&ga, 0, sizeof(ga));
+        ga.A = x.data_ptr(); ga.B = w.data_ptr(); ga.C = y.data_ptr();
+        ga.M = B * H * W; ga.N = (int)N; ga.K = (int)C;
+        ga.lda = (int)C; ga.ldb = (int)C; ga.ldc = (int)N;
+        Tensor slab, stats;
+        const int m_tiles = gemm_m_tiles(ga.M);
+        if (want_stats) {
+            slab = at::empty({m_tiles, 2 * N}, x.options().dtype(at::kFloat));
+            ga.conv_mode = 1;
+            ga.stats_slab = slab.data_ptr<float>();
+        }
+        launch_gemm_nt(ga, cur_stream(x));
+        if (want_stats) stats = shrink_rows(slab, m_tiles, 2 * N, kMaxFinalizeRows).view({-1, 2, N});
+        return {y, stats};
+    }
     TORCH_CHECK((long)y.numel() * 2 < (1L << 31), "output exceeds 2 GiB");
     ConvGeom g;
     std::memset(&g, 0, sizeof(g));
@@ -180,6 +217,41 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
         g.is = 1; g.wtaps = KH * KW;
         return g;
     };
+    if (stride == 1 && !(addend_ptr && addend_stride == 2) && conv_gemm_core_ok(N, C, KH, KW, stride, pad, cfg)) {
+        // dx[M,Cin] = dy[M,Cout] . wt[Cin,Cout]^T on the GEMM core
+        Tensor dx = empty_nhwc(B, C, H, W, dy);
+        GemmArgs ga;
+        std::memset(&ga, 0, sizeof(ga));
+        ga.A = dy.data_ptr(); ga.B = wt.data_ptr(); ga.C = dx.data_ptr();
+        ga.M = B * H * W; ga.N = (int)C; ga.K = (int)N;
+        ga.lda = (int)N; ga.ldb = (int)N; ga.ldc = (int)C;
+        Tensor psums, slab;
+        const int m_tiles = gemm_m_tiles(ga.M);
+        if (addend_ptr || bnr) {
+            ga.conv_mode = 2;
+            ga.addend = addend_ptr;
+            ga.addend_mask = addend_mask_ptr;
+        }
+        if (bnr) {
+            check_nhwc_bf16(*bn_x, "bn_x");
+            TORCH_CHECK(bn_x->sizes().vec() == x_shape, "bn_x must have the shape of dx");
+            TORCH_CHECK(bn_mask.has_value() && bn_mask->is_cuda() && bn_mask->scalar_type() == at::kByte &&
+                            bn_mask->is_contiguous() && bn_mask->numel() == B * H * W * (C / 8),
+                        "bn_mask: expected contiguous uint8 [B*H*W, C/8]");
+            TORCH_CHECK(bn_mean.has_value() && bn_invstd.has_value(), "bn_mean / bn_invstd missing");
+            check_vec_f32(*bn_mean, C, "bn_mean"); check_vec_f32(*bn_invstd, C, "bn_invstd");
+            ga.bnr_x = bn_x->data_ptr();
+            ga.bnr_mask = bn_mask->data_ptr<uint8_t>();
+            ga.bnr_mean = bn_mean->data_ptr<float>();
+            ga.bnr_invstd = bn_invstd->data_ptr<float>();
+            slab = at::empty({m_tiles, 2 * C}, dy.options().dtype(at::kFloat));
+            ga.stats_slab = slab.data_ptr<float>();
+        }
+        launch_gemm_nt(ga, s);
+        if (bnr) psums = shrink_rows(slab, m_tiles, 2 * C, kReduceChunks).view({-1, 2, C});
+        return {dx, psums};
+    }
+    if (cfg == kCfgGemmCore) cfg = 0;  // (compact stride-2 addend: implicit-GEMM kernel only)
     if (stride == 1) {
         Tensor dx = empty_nhwc(B, C, H, W, dy);
         TORCH_CHECK((long)dx.numel() * 2 < (1L << 31), "dx exceeds 2 GiB");

@@ -73,8 +73,16 @@ __device__ __forceinline__ int stage_off(int s) { return s ? STAGE1_OFF : 0; }
 // Persistent: gridDim.x workgroups (one per CU) walk the tile list.  Blocks b and b+8 share an XCD; every XCD label
 // gets a contiguous range of tiles so that the workgroups that run together on one L2 share operand panels.
 // EXTRA: 0 none, 1 residual added, 2 multiplied by GELU'(gelu_in).  ACT: GELU, the pre-activation is written too.
+// CONV (the GEMM is a pointwise convolution in NHWC, ld == channels):
+//   1  forward: per-column sum and sum of squares of the ROUNDED outputs (BatchNorm statistics) -> slab[m_tile][2][N]
+//   2  data gradient: + addend gated by a bit mask (the residual branch's gradient through a ReLU), and the two
+//      BatchNorm-backward sums of the result (sum g, sum g * xhat with g = result gated by the BN's ReLU mask)
+//      -> slab[m_tile][2][N]; which of the two parts run is a launch argument.
 // Compile-time so that the K loop does not carry a dozen wave-uniform conditions in scalar registers.
-template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED>
+// (A variant in which waves 0-3 issued all operand DMA and waves 4-7 all output stores, so that no wave's counted
+// wait on its DMA also waits for its own older stores, measured within 2 % of this one on every pointwise shape of
+// ResNet-50 and on 4096^3: the store drain is not what short reductions wait for, and it was dropped.)
+template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,14 +100,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
 
     // ---- per-tile operand state (A/B side), recomputed for the NEXT tile while the current one is being stored
     i32x4 ra, rb;
-    uint32_t voffA[2][2], voffB[2][2];
     long m0;
-    int n0, rows_m, tile_m;
+    int n0, rows_m, rows_n, tile_m;
+    // DMA source offsets: in every phase each thread fetches 2 pieces of one half-tile.  Piece pc = wave * 2 + j
+    // covers rows pc*8 .. pc*8+7 (1 KiB); lane -> row pc*8 + lane/8, physical chunk lane%8, which holds logical
+    // chunk (lane%8) ^ ((row >> 1) & 7).  The per-lane part of the address is the same for every tile and K-tile
+    // (2 + 2 registers); the half (128 rows) and the K-tile go into the instruction's scalar offset, which the
+    // range check of the descriptor does not see: rows past the end of a ragged tile are masked explicitly.
     int lch[2];
+    uint32_t vA[2], vB[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = (wave * 2 + j) * 8 + (lane >> 3);
         lch[j] = (lane & 7) ^ ((row >> 1) & 7);
+        vA[j] = (uint32_t)row * (uint32_t)(a.lda * 2) + (uint32_t)(lch[j] * 16);
+        vB[j] = (uint32_t)row * (uint32_t)(a.ldb * 2) + (uint32_t)(lch[j] * 16);
     }
     auto setup = [&](int idx) {
         // grouped order: bands of a.group_m tile rows, m fastest inside a band (group_m = 1: n fastest)
@@ -112,23 +127,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
         m0 = (long)tile_m * BM;
         n0 = tn * BN;
         rows_m = (int)((a.M - m0) < BM ? (a.M - m0) : BM);
-        const int rows_n = (a.N - n0) < BN ? (a.N - n0) : BN;
+        rows_n = (a.N - n0) < BN ? (a.N - n0) : BN;
         // descriptors re-based at the tile's first row: offsets inside stay far below 2^31
         ra = make_rsrc_words(static_cast<const char*>(a.A) + m0 * a.lda * 2, (uint32_t)((long)rows_m * a.lda * 2));
         rb = make_rsrc_words(static_cast<const char*>(a.B) + (long)n0 * a.ldb * 2, (uint32_t)((long)rows_n * a.ldb * 2));
-        // DMA source offsets: in every phase each thread issues 2 pieces (j = 0, 1) of one half-tile.  Piece
-        // pc = wave * 2 + j covers rows pc*8 .. pc*8+7 (1 KiB); lane -> row pc*8 + lane/8, physical chunk lane%8,
-        // which holds logical chunk (lane%8) ^ ((row >> 1) & 7).
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = (wave * 2 + j) * 8 + (lane >> 3);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = h * 128 + row;
-                voffA[h][j] = r < rows_m ? (uint32_t)r * (uint32_t)(a.lda * 2) + (uint32_t)(lch[j] * 16) : kOOB;
-                voffB[h][j] = r < rows_n ? (uint32_t)r * (uint32_t)(a.ldb * 2) + (uint32_t)(lch[j] * 16) : kOOB;
-            }
-        }
     };
     const uint32_t piece_base = lds_address(smem) + (uint32_t)wave * 2048u;  // + j * 1024
 
@@ -136,21 +138,19 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
     // slot: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi; t = K-tile of the current operand state; par = its stage buffer
     auto issue = [&](int hslot, int t, int par) {
         const uint32_t dst = piece_base + (uint32_t)(stage_off(par) + hslot * HALF_BYTES);
-        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(t * BK * 2);
         const bool isB = hslot >= 2;
         const int h = hslot & 1;
-        uint32_t v0 = isB ? voffB[h][0] : voffA[h][0];
-        uint32_t v1 = isB ? voffB[h][1] : voffA[h][1];
-        if (RAGGED && t == nt - 1) {  // chunks past the end of the reduction axis read zeros
-            if (t * BK + lch[0] * 8 >= a.K) v0 = kOOB;
-            if (t * BK + lch[1] * 8 >= a.K) v1 = kOOB;
-        }
-        if (isB) {
-            lds_dma16s(rb, v0, soff, dst);
-            lds_dma16s(rb, v1, soff, dst + 1024u);
-        } else {
-            lds_dma16s(ra, v0, soff, dst);
-            lds_dma16s(ra, v1, soff, dst + 1024u);
+        const int ld2 = (isB ? a.ldb : a.lda) * 2;
+        const int rows = isB ? rows_n : rows_m;
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(t * BK * 2 + h * 128 * ld2);
+        const bool cut0 = RAGGED && t == nt - 1 && t * BK + lch[0] * 8 >= a.K;  // chunks past the end of the
+        const bool cut1 = RAGGED && t == nt - 1 && t * BK + lch[1] * 8 >= a.K;  // reduction axis read zeros
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = h * 128 + (wave * 2 + j) * 8 + (lane >> 3);
+            uint32_t v = isB ? vB[j] : vA[j];
+            if (r >= rows || (j ? cut1 : cut0)) v = kOOB;
+            lds_dma16s(isB ? rb : ra, v, soff, dst + (uint32_t)(j * 1024));
         }
     };
 
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
         b_off[ks] = 2 * HALF_BYTES + (wc >> 1) * HALF_BYTES + (wc & 1) * 64 * 128 + lo;
     }
     const int och = tid & 31, orow = tid >> 5;  // store pass: 32 chunks of 8 columns per row, 16 rows per pass
+    constexpr int PB = CONV == 2 ? 4 : 8;       // passes whose global reads are in flight together
 
     // ---- prologue of the first tile: K-tile 0
     int gk = 0;  // K-tiles consumed so far: K-tile t of the current tile lives in stage (gk + t) & 1
@@ -250,17 +251,34 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
         char* Os = smem + (npar == 0 ? EXTRA_OFF : 0);
         const int ncol = on0 + och * 8;
         const bool col_ok = ncol < a.N;  // N % 8 == 0
-        const uint32_t cbytes = (uint32_t)((long)orows_m * a.ldc * 2);
+        const uint32_t cbytes = a.debug_nostore ? 0u : (uint32_t)((long)orows_m * a.ldc * 2);
         const __amdgpu_buffer_rsrc_t rc = make_rsrc(static_cast<char*>(a.C) + om0 * a.ldc * 2, cbytes);
         const __amdgpu_buffer_rsrc_t rp = make_rsrc(ACT ? static_cast<char*>(a.preact_out) + om0 * a.ldc * 2 : nullptr, ACT ? cbytes : 0u);
-        // one optional extra operand: the residual (added) or the GELU input (its derivative multiplies)
-        const void* extra = EXTRA == 1 ? a.residual : a.gelu_in;
-        const int lde = EXTRA == 1 ? a.ldr : a.ldu;
-        const __amdgpu_buffer_rsrc_t re = make_rsrc(EXTRA ? static_cast<const char*>(extra) + om0 * lde * 2 : nullptr,
-                                                    EXTRA ? (uint32_t)((long)orows_m * lde * 2) : 0u);
-        float csum[8];
+        // one optional extra bf16 operand: the residual / gated addend (added) or the GELU input (its derivative
+        // multiplies); the fused BN-backward sums read one more (the BN's input) and the two bit masks
+        const bool has_add = CONV == 2 && a.addend != nullptr, has_amask = CONV == 2 && a.addend_mask != nullptr;
+        const bool bnr = CONV == 2 && a.bnr_x != nullptr;
+        const void* extra = CONV == 2 ? a.addend : (EXTRA == 1 ? a.residual : a.gelu_in);
+        const int lde = CONV == 2 ? a.ldc : (EXTRA == 1 ? a.ldr : a.ldu);
+        const bool use_extra = EXTRA != 0 || has_add;
+        const __amdgpu_buffer_rsrc_t re = make_rsrc(use_extra ? static_cast<const char*>(extra) + om0 * lde * 2 : nullptr,
+                                                    use_extra ? (uint32_t)((long)orows_m * lde * 2) : 0u);
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(bnr ? static_cast<const char*>(a.bnr_x) + om0 * a.ldc * 2 : nullptr,
+                                                    bnr ? (uint32_t)((long)orows_m * a.ldc * 2) : 0u);
+        // masks: one bit per element, [pixel][C/8] bytes (ldc == N for the convolution modes)
+        const uint8_t* amask = has_amask ? a.addend_mask + ((om0 * a.ldc) >> 3) : nullptr;
+        const uint8_t* bmask = bnr ? a.bnr_mask + ((om0 * a.ldc) >> 3) : nullptr;
+        constexpr bool SUMS2 = CONV != 0;  // two per-column sums instead of one
+        float csum[8], csq[SUMS2 ? 8 : 1], mu[CONV == 2 ? 8 : 1], is[CONV == 2 ? 8 : 1];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) csum[k] = 0.f;
+        for (int k = 0; k < 8; ++k) {
+            csum[k] = 0.f;
+            if (SUMS2) csq[k] = 0.f;
+            if (CONV == 2) {
+                mu[k] = bnr && col_ok ? a.bnr_mean[ncol + k] : 0.f;
+                is[k] = bnr && col_ok ? a.bnr_invstd[ncol + k] : 0.f;
+            }
+        }
 
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
                     const int n = on0 + wcol + j * 16;
-                    if (a.bias != nullptr && n < a.N) bv = *reinterpret_cast<const f32x4_t*>(a.bias + n);  // N % 4 == 0
+                    if (CONV == 0 && a.bias != nullptr && n < a.N) bv = *reinterpret_cast<const f32x4_t*>(a.bias + n);  // N % 4 == 0
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const f32x4_t v = acc[i][j] + bv;
@@ -282,74 +300,129 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            // coalesced pass over 128 rows: 8 passes of 16 rows, 16 B per lane.  Everything read from global memory is
-            // fetched for all passes first; every thread issues the same number of stores (masked ones are dropped by
-            // the descriptor's range check), so a counted wait can tell the next tile's DMA from the stores behind it.
-            bf16x8 ev[8];
-            uint32_t coff[8];
+            // coalesced pass over 128 rows: 8 passes of 16 rows, 16 B per lane, in batches of PB passes.  Everything
+            // read from global memory is fetched for a whole batch first; every thread issues one store per pass
+            // (masked ones are dropped by the descriptor's range check).
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int row = hh * 128 + p * 16 + orow;
-                coff[p] = col_ok ? (uint32_t)row * (uint32_t)(a.ldc * 2) + (uint32_t)(ncol * 2) : kOOB;
-            }
-            if (EXTRA != 0) {
+            for (int pb = 0; pb < 8; pb += PB) {
+                bf16x8 ev[PB], bx[CONV == 2 ? PB : 1];
+                unsigned abits[CONV == 2 ? PB : 1], bbits[CONV == 2 ? PB : 1];
+                uint32_t coff[PB];
 #pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    const int row = hh * 128 + p * 16 + orow;
-                    ev[p] = buffer_load_bf16x8(re, col_ok ? (uint32_t)row * (uint32_t)(lde * 2) + (uint32_t)(ncol * 2) : kOOB);
+                for (int p = 0; p < PB; ++p) {
+                    const int row = hh * 128 + (pb + p) * 16 + orow;
+                    coff[p] = col_ok ? (uint32_t)row * (uint32_t)(a.ldc * 2) + (uint32_t)(ncol * 2) : kOOB;
                 }
-            }
+                if (EXTRA != 0 || CONV == 2) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int lrow = p * 16 + orow;
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + lrow * OPITCH + och * 16);
-                if (ACT)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, coff[p], 0, 0);
-                if (ACT) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (bf16)gelu_f((float)v[k]);
+                    for (int p = 0; p < PB; ++p) {
+                        const int row = hh * 128 + (pb + p) * 16 + orow;
+                        const uint32_t eo = col_ok ? (uint32_t)row * (uint32_t)(lde * 2) + (uint32_t)(ncol * 2) : kOOB;
+                        if (EXTRA != 0 || has_add) ev[p] = buffer_load_bf16x8(re, eo);
+                        if (CONV == 2) {
+                            const bool in = col_ok && row < orows_m;
+                            abits[p] = has_add ? 0xffu : 0u;
+                            if (has_amask) abits[p] = in ? amask[eo >> 4] : 0u;
+                            bbits[p] = 0u;
+                            if (bnr) {
+                                bx[p] = buffer_load_bf16x8(rx, eo);
+                                bbits[p] = in ? bmask[eo >> 4] : 0u;
+                            }
+                        }
+                    }
                 }
-                if (EXTRA == 2) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] * gelu_grad_f((float)ev[p][k]));
-                }
-                if (EXTRA == 1) {
+                for (int p = 0; p < PB; ++p) {
+                    const int lrow = (pb + p) * 16 + orow;
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + lrow * OPITCH + och * 16);
+                    if (ACT)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, coff[p], 0, 0);
+                    if (ACT) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)ev[p][k]);
-                }
-                if (COLSUM && hh * 128 + lrow < orows_m) {
+                        for (int k = 0; k < 8; ++k) v[k] = (bf16)gelu_f((float)v[k]);
+                    }
+                    if (EXTRA == 2) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) csum[k] += (float)v[k];
+                        for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] * gelu_grad_f((float)ev[p][k]));
+                    }
+                    if (EXTRA == 1) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)ev[p][k]);
+                    }
+                    if (COLSUM && hh * 128 + lrow < orows_m) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) csum[k] += (float)v[k];
+                    }
+                    if (CONV == 1) {  // (rows past M are zeros: their A rows were)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float f = (float)v[k];
+                            csum[k] += f;
+                            csq[k] += f * f;
+                        }
+                    }
+                    if (CONV == 2) {
+                        if (has_add) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                                v[k] = (bf16)((float)v[k] + (((abits[p] >> k) & 1u) ? (float)ev[p][k] : 0.f));
+                        }
+                        if (bnr) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const float gg = ((bbits[p] >> k) & 1u) ? (float)v[k] : 0.f;
+                                csum[k] += gg;
+                                csq[k] += gg * ((float)bx[p][k] - mu[k]) * is[k];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, coff[p], 0, 0);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, coff[p], 0, 0);
             }
             if (hh == 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();  // the staged rows are read before the other half overwrites them
             }
         }
-        // the next tile's first K-tile (issued before the 16 / 32 stores of this thread) has landed
+        // The next tile's first K-tile was issued before this thread's 16 (32 with the pre-activation) stores and
+        // vmcnt retires in issue order: at most that many operations outstanding means the DMA has landed.
         if (ACT) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        if (COLSUM) {
-            // per-tile column sums of what was stored (bias gradient of the layer that produced this gradient):
-            // threads och + 32 * r own the same 8 columns: lanes l and l^32 in a wave, then the 8 waves through LDS
+        const bool want_sums = COLSUM || CONV == 1 || (CONV == 2 && bnr);
+        if (want_sums) {
+            // per-tile column sums of what was stored: threads och + 32 * r own the same 8 columns: lanes l and
+            // l^32 in a wave, then the 8 waves through LDS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             float* Ss = reinterpret_cast<float*>(Os);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) csum[k] += __shfl_xor(csum[k], 32, 64);
+            for (int k = 0; k < 8; ++k) {
+                csum[k] += __shfl_xor(csum[k], 32, 64);
+                if (SUMS2) csq[k] += __shfl_xor(csq[k], 32, 64);
+            }
             if (lane < 32) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) Ss[wave * BN + och * 8 + k] = csum[k];
+                for (int k = 0; k < 8; ++k) {
+                    Ss[wave * BN + och * 8 + k] = csum[k];
+                    if (SUMS2) Ss[(8 + wave) * BN + och * 8 + k] = csq[k];
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (tid < BN && on0 + tid < a.N) {
-                float s = 0.f;
+                float s = 0.f, q = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) s += Ss[w * BN + tid];
-                a.colsum_slab[(long)otile_m * a.N + on0 + tid] = s;
+                for (int w = 0; w < 8; ++w) {
+                    s += Ss[w * BN + tid];
+                    if (SUMS2) q += Ss[(8 + w) * BN + tid];
+                }
+                if (SUMS2) {
+                    float* dst = a.stats_slab + (long)otile_m * 2 * a.N;
+                    dst[on0 + tid] = s;
+                    dst[a.N + on0 + tid] = q;
+                } else {
+                    a.colsum_slab[(long)otile_m * a.N + on0 + tid] = s;
+                }
             }
         }
         if (!has_next) break;
@@ -362,15 +435,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
 
 int gemm_m_tiles(long M) { return (int)((M + BM - 1) / BM); }
 
-template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED>
+template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV>
 static void launch_variant(const GemmArgs& a, int grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED>),
+        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV>), dim3(grid), dim3(512), LDS_BYTES, s, a);
 }
 
 void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
@@ -381,6 +454,8 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
     // 32 tiles run together on one XCD: with many tile columns walk bands of 4 tile rows (4 A panels + 8 B panels
     // per K-step instead of 1 + 32)
     a.group_m = a.n_tiles > 12 ? 4 : 1;
+    static const bool nostore = std::getenv("PDT_GEMM_NOSTORE") != nullptr;  // timing diagnostics only
+    a.debug_nostore = nostore ? 1 : 0;
     const int total = a.m_tiles * a.n_tiles;
     static const int cus = [] {
         int dev = 0, n = 256;
@@ -392,16 +467,30 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
     const bool ragged = a.K % BK != 0, colsum = a.colsum_slab != nullptr;
     const int extra = a.residual ? 1 : (a.gelu_in ? 2 : 0);
     const bool act = a.act == 1;
+    if (a.conv_mode != 0) {
+        // pointwise convolution in NHWC: dense rows (ld == channels), no bias
+        const bool fused = a.addend || a.bnr_x;
+        if (ragged || extra || act || colsum || a.bias || a.ldc != a.N || (a.conv_mode == 1 && !a.stats_slab) ||
+            (a.conv_mode == 2 && (!fused || (a.bnr_x && !(a.stats_slab && a.bnr_mask && a.bnr_mean && a.bnr_invstd)) ||
+                                  (a.addend_mask && !a.addend))) ||
+            a.conv_mode > 2) {
+            fprintf(stderr, "launch_gemm_nt: unsupported convolution epilogue\n");
+            abort();
+        }
+        if (a.conv_mode == 1) launch_variant<0, false, false, false, 1>(a, grid, s);
+        else launch_variant<0, false, false, false, 2>(a, grid, s);
+        return;
+    }
     if ((a.residual && a.gelu_in) || (act && (extra || colsum || !a.preact_out)) || (!act && a.preact_out) ||
         (ragged && (extra || act))) {
         fprintf(stderr, "launch_gemm_nt: unsupported epilogue combination\n");
         abort();
     }
-    if (act) launch_variant<0, true, false, false>(a, grid, s);
-    else if (extra == 1) colsum ? launch_variant<1, false, true, false>(a, grid, s) : launch_variant<1, false, false, false>(a, grid, s);
-    else if (extra == 2) colsum ? launch_variant<2, false, true, false>(a, grid, s) : launch_variant<2, false, false, false>(a, grid, s);
-    else if (ragged) colsum ? launch_variant<0, false, true, true>(a, grid, s) : launch_variant<0, false, false, true>(a, grid, s);
-    else colsum ? launch_variant<0, false, true, false>(a, grid, s) : launch_variant<0, false, false, false>(a, grid, s);
+    if (act) launch_variant<0, true, false, false, 0>(a, grid, s);
+    else if (extra == 1) colsum ? launch_variant<1, false, true, false, 0>(a, grid, s) : launch_variant<1, false, false, false, 0>(a, grid, s);
+    else if (extra == 2) colsum ? launch_variant<2, false, true, false, 0>(a, grid, s) : launch_variant<2, false, false, false, 0>(a, grid, s);
+    else if (ragged) colsum ? launch_variant<0, false, true, true, 0>(a, grid, s) : launch_variant<0, false, false, true, 0>(a, grid, s);
+    else colsum ? launch_variant<0, false, true, false, 0>(a, grid, s) : launch_variant<0, false, false, false, 0>(a, grid, s);
 }
 
 }  // namespace pdt

@@ -216,7 +216,18 @@ struct GemmArgs {
     void* preact_out;      // [M][ldc] bf16 or null: the value before the activation is written here too
     int act;               // 0 none, 1 GELU (erf form)
     float* colsum_slab;    // [m_tiles][N] fp32 or null: per-m-tile column sums of the stored values
+    // pointwise convolution in NHWC (ld == channels, no bias): 1 = forward with the BatchNorm statistics of the
+    // rounded output, 2 = data gradient with a gated addend and / or the fused BatchNorm-backward sums
+    int conv_mode;
+    float* stats_slab;           // [m_tiles][2][N] fp32: mode 1 (sum, sum of squares), mode 2 with bnr_x (sum g, sum g*xhat)
+    const void* addend;          // [M][N] bf16 or null
+    const uint8_t* addend_mask;  // [M][N/8] one bit per element or null (ungated)
+    const void* bnr_x;           // [M][N] bf16 or null: input of the BatchNorm whose backward sums are taken
+    const uint8_t* bnr_mask;     // [M][N/8]: activity of the ReLU behind that BatchNorm
+    const float* bnr_mean;       // [N]
+    const float* bnr_invstd;     // [N]
     int m_tiles, n_tiles, group_m;  // filled by the launcher
+    int debug_nostore;              // timing diagnostics: the output descriptor gets zero records (stores dropped)
 };
 int gemm_m_tiles(long M);
 void launch_gemm_nt(const GemmArgs& a, hipStream_t s);

@@ -78,6 +78,20 @@ def test_conv_every_igemm_build_forced(kc, cfg, case):
     _assert_all_ok(kc, n)
 
 
+# Pointwise stride-1 convolutions on the GEMM core (gemm.hip: 256x256 tiles, persistent grid), which the bindings pick
+# when the output channels fill its tile: forced here also on narrow / ragged shapes (M % 256 != 0, N = 64 .. 640,
+# K = 64 .. 2048): forward + BN statistics, data gradient plain / + gated addend / + fused BN-backward sums (against
+# the implicit-GEMM kernel and the separate reduce kernel).
+@pytest.mark.parametrize("case", [
+    (2, 64, 8, 8, 64, 1, 1, 0), (5, 64, 23, 23, 256, 1, 1, 0), (5, 256, 19, 19, 64, 1, 1, 0),
+    (3, 128, 21, 21, 512, 1, 1, 0), (2, 512, 7, 7, 2048, 1, 1, 0), (2, 2048, 7, 7, 512, 1, 1, 0),
+    (9, 512, 14, 14, 640, 1, 1, 0), (16, 256, 56, 56, 64, 1, 1, 0), (16, 64, 56, 56, 256, 1, 1, 0)])
+def test_pointwise_conv_on_gemm_core_forced(kc, case):
+    n = len(kc.RESULTS)
+    kc.check_conv(case, False, cfg=kc.GEMM_CORE)
+    _assert_all_ok(kc, n)
+
+
 @pytest.mark.parametrize("case,splits", [
     ((3, 128, 21, 21, 128, 3, 1, 1), 7), ((5, 256, 9, 9, 1024, 1, 1, 0), 5), ((2, 64, 30, 30, 64, 3, 1, 1), 13),
     ((3, 64, 23, 23, 128, 1, 1, 0), 9), ((3, 128, 20, 20, 64, 3, 2, 1), 4), ((2, 512, 7, 7, 512, 3, 1, 1), 3)])
