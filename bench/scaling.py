@@ -22,7 +22,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-LINK_GBPS = 153.0          # xGMI per-link bandwidth (task brief; calibrate with a 2-GPU copy)
+# Defaults from the task brief, NOT measured on this pool (it exposes one GPU per job): `--calibration FILE` replaces
+# them with what bench/micro/rccl_busbw.py measured on the node at hand (bus bandwidth, latency, bucket size).
+LINK_GBPS = 153.0          # xGMI per-link bandwidth
 COLL_LATENCY_US = 25.0     # launch + sync latency per RCCL collective (10-30 us)
 IPC_SMALL_US = 12.0        # one IpcAllReduce kernel (measured launch-to-launch with 2 processes on one MI355X;
                            # across xGMI add the store round trip, a few us): the SyncBN statistics path
@@ -76,16 +78,24 @@ def main() -> int:
     ap.add_argument("--syncbn_comm", default="ipc", choices=["ipc", "rccl"],
                     help="modelled path of the SyncBN statistics all-reduce (parallel/ipc.py)")
     ap.add_argument("--model-from", dest="model_from", default=None, help="bench.py JSON line/log of a 1-GPU run")
+    ap.add_argument("--calibration", default=None, help="JSON written by bench/micro/rccl_busbw.py --out")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
+    bucket_mb = 16.0
+    if a.calibration:
+        global LINK_GBPS, COLL_LATENCY_US
+        cal = json.loads(open(a.calibration).read().strip().splitlines()[-1])
+        LINK_GBPS, COLL_LATENCY_US = float(cal["link_GBps"]), float(cal["collective_latency_us"])
+        bucket_mb = float(cal.get("bucket_mb", bucket_mb))
     if a.model_from:
         line = [l for l in open(a.model_from).read().splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
         assert d["n_gpus"] == 1
         batch = d["config"]["per_gpu_batch"]
         result = {"source": a.model_from, "link_GBps": LINK_GBPS, "collective_latency_us": COLL_LATENCY_US,
-                  "ring": model_curve(d["ms_per_step"], batch, a.sync_bn, algo="ring", syncbn_comm=a.syncbn_comm),
-                  "direct": model_curve(d["ms_per_step"], batch, a.sync_bn, algo="direct", syncbn_comm=a.syncbn_comm)}
+                  "constants": "calibrated: " + a.calibration if a.calibration else "task-brief defaults (unmeasured)",
+                  "ring": model_curve(d["ms_per_step"], batch, a.sync_bn, bucket_mb, "ring", a.syncbn_comm),
+                  "direct": model_curve(d["ms_per_step"], batch, a.sync_bn, bucket_mb, "direct", a.syncbn_comm)}
     else:
         import torch
 

@@ -66,3 +66,25 @@ def test_gpus_flag_must_match_world_size(free_port):
            "127.0.0.1", "--master-port", str(free_port), os.path.join(ROOT, "bench.py"), "--gpus", "4", *SMALL]
     p = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
+
+
+def test_rccl_busbw_calibration_feeds_the_scaling_model(tmp_path, free_port):
+    """bench/micro/rccl_busbw.py (all-reduce sweep -> link_GBps / latency / bucket size) on 2 gloo ranks, and
+    bench/scaling.py --calibration replacing its task-brief constants with that file."""
+    cal = tmp_path / "cal.json"
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench", "micro", "rccl_busbw.py"), "--gpus", "2",
+                          "--backend", "gloo", "--device", "cpu", "--sizes_mb", "1", "2", "--iters", "3", "--warmup", "1",
+                          "--port", str(free_port), "--out", str(cal)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    doc = json.loads(cal.read_text())
+    assert doc["world"] == 2 and doc["link_GBps"] > 0 and doc["collective_latency_us"] > 0 and doc["bucket_mb"] in (1, 2)
+    assert len(doc["rows"]) == 1 and len(doc["rows"][0]["rows"]) == 3  # 4 KiB latency row + two sizes
+    line = tmp_path / "bench.log"
+    line.write_text(json.dumps({"n_gpus": 1, "ms_per_step": 95.0, "config": {"per_gpu_batch": 1280}}) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench", "scaling.py"), "--model-from", str(line),
+                          "--calibration", str(cal)], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout)
+    assert res["link_GBps"] == doc["link_GBps"] and res["constants"].startswith("calibrated")
+    assert [r["n_gpus"] for r in res["ring"]] == [1, 2, 4, 8]
