@@ -39,11 +39,12 @@ def main(argv=None) -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    # per-GPU batch sized for 288 GB HBM3E: 1280 is what the memory model (utils/memory.py) picks for ResNet-50 at
-    # 224x224: ~125 GB of bf16 activations, bounded by the 2 GiB buffer-descriptor range of the stem output (1337
-    # images), not by memory; every conv launch has >12 rounds of tiles per CU (no tail effect) and the gradient
-    # all-reduce is <2 % of the step.  Measured: 13.46k img/s at 1280, 13.33k at 1024, 11.2k at 256.
-    ap.add_argument("--batch_size", type=int, default=1280,
+    # per-GPU batch sized for 288 GB HBM3E: ~125 GB of bf16 activations at 1280 for ResNet-50 at 224x224; every conv
+    # launch has >12 rounds of tiles per CU (no tail effect) and the gradient all-reduce is <2 % of the step.
+    # Larger batches run too (activations beyond one 2 GiB buffer descriptor are launched in batch chunks, the
+    # memory model allows ~2.7k): 13.7k img/s at 1280, 13.9k at 2048 (default, ~200 GB), 14.0k at 2560, see
+    # profiles/r2_batch_sweep.md.
+    ap.add_argument("--batch_size", type=int, default=2048,
                     help="per-GPU batch; 0 = size it from the memory model (utils/memory.py)")
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--image_size", type=int, default=224)

@@ -25,12 +25,36 @@ using at::Tensor;
 
 hipStream_t cur_stream(const Tensor& t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
+// The convolution / pooling kernels address one operand through a 32-bit buffer descriptor (range-checked loads are
+// what gives them zero padding and ragged tiles for free), so ONE LAUNCH sees at most 2 GiB of each operand.  A
+// batch whose activations are larger (56x56x256 bf16 is 1.6 MB per image: 2 GiB at B = 1337) is cut into batch
+// chunks HERE: NHWC keeps a sub-range of images contiguous, every kernel is independent per image, and the
+// per-launch partial rows (BatchNorm statistics, split-K slabs) of the chunks are simply stacked.  The BatchNorm,
+// GEMM and elementwise kernels use 64-bit addressing and take the whole tensor.
+long g_window_bytes = (1L << 31) - 4096;
+void set_activation_window(int64_t bytes) {
+    TORCH_CHECK(bytes >= 4096 && bytes < (1L << 31), "activation window: 4 KiB .. 2 GiB");
+    g_window_bytes = bytes;
+}
+// images per launch such that the largest per-image operand (bytes) stays inside the window
+long chunk_images(long B, long bytes_per_image) {
+    TORCH_CHECK(bytes_per_image <= g_window_bytes, "one image of ", bytes_per_image,
+                " bytes exceeds the buffer-descriptor window of ", g_window_bytes, " bytes");
+    const long per = g_window_bytes / std::max<long>(bytes_per_image, 1);
+    return std::max<long>(1, std::min(per, B));
+}
+inline const char* at_image(const void* p, long b0, long bytes_per_image) {
+    return p ? static_cast<const char*>(p) + b0 * bytes_per_image : nullptr;
+}
+inline char* at_image(void* p, long b0, long bytes_per_image) {
+    return p ? static_cast<char*>(p) + b0 * bytes_per_image : nullptr;
+}
+
 void check_nhwc_bf16(const Tensor& t, const char* name) {
     TORCH_CHECK(t.is_cuda(), name, ": expected a GPU tensor");
     TORCH_CHECK(t.scalar_type() == at::kBFloat16, name, ": expected bf16, got ", t.scalar_type());
     TORCH_CHECK(t.dim() == 4, name, ": expected 4-D [B,C,H,W]");
     TORCH_CHECK(t.is_contiguous(at::MemoryFormat::ChannelsLast), name, ": expected channels_last (NHWC) memory");
-    TORCH_CHECK((long)t.numel() * 2 < (1L << 31), name, ": tensor exceeds the 2 GiB buffer-descriptor range");
     TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, ": data pointer must be 16-B aligned");
 }
 void check_vec_f32(const Tensor& t, long n, const char* name) {
@@ -137,7 +161,6 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
         if (want_stats) stats = shrink_rows(slab, m_tiles, 2 * N, kMaxFinalizeRows).view({-1, 2, N});
         return {y, stats};
     }
-    TORCH_CHECK((long)y.numel() * 2 < (1L << 31), "output exceeds 2 GiB");
     ConvGeom g;
     std::memset(&g, 0, sizeof(g));
     g.B = B; g.Hin = H; g.Win = W; g.C = C; g.Hout = Ho; g.Wout = Wo; g.N = N;
@@ -148,15 +171,28 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
             const int t = r * KW + s;
             g.set_tap(t, r - (int)pad, s - (int)pad, t);
         }
-    Tensor stats;
+    const long x_img = H * W * C * 2, y_img = Ho * Wo * N * 2;
+    const long per = chunk_images(B, std::max(x_img, y_img));
+    std::vector<int> tiles;
+    int m_tiles = 0;
+    for (long b0 = 0; b0 < B; b0 += per) {
+        g.B = (int)std::min(per, B - b0);
+        tiles.push_back(conv_igemm_m_tiles(g, nullptr, (int)cfg));
+        m_tiles += tiles.back();
+    }
+    Tensor stats, slab;
     float* slab_ptr = nullptr;
-    Tensor slab;
-    int m_tiles = conv_igemm_m_tiles(g, nullptr, (int)cfg);
     if (want_stats) {
         slab = at::empty({m_tiles, 2 * N}, x.options().dtype(at::kFloat));
         slab_ptr = slab.data_ptr<float>();
     }
-    launch_conv_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), g, slab_ptr, cur_stream(x), (int)cfg);
+    long row = 0, ci = 0;
+    for (long b0 = 0; b0 < B; b0 += per, ++ci) {
+        g.B = (int)std::min(per, B - b0);
+        launch_conv_igemm(at_image(x.data_ptr(), b0, x_img), w.data_ptr(), at_image(y.data_ptr(), b0, y_img), g,
+                          slab_ptr ? slab_ptr + row * 2 * N : nullptr, cur_stream(x), (int)cfg);
+        row += tiles[ci];
+    }
     if (want_stats) stats = shrink_rows(slab, m_tiles, 2 * N, kMaxFinalizeRows).view({-1, 2, N});
     return {y, stats};
 }
@@ -252,9 +288,10 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
         return {dx, psums};
     }
     if (cfg == kCfgGemmCore) cfg = 0;  // (compact stride-2 addend: implicit-GEMM kernel only)
+    const long dy_img = Ho * Wo * N * 2, dx_img = H * W * C * 2;
+    const long per = chunk_images(B, std::max(dy_img, dx_img));
     if (stride == 1) {
         Tensor dx = empty_nhwc(B, C, H, W, dy);
-        TORCH_CHECK((long)dx.numel() * 2 < (1L << 31), "dx exceeds 2 GiB");
         ConvGeom g = base_geom();
         g.nOH = H; g.nOW = W; g.os = 1;
         g.ntaps = KH * KW;
@@ -266,9 +303,8 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
         g.addend = addend_ptr;
         g.addend_mask = addend_mask_ptr;
         g.addend_stride = (int)addend_stride;
-        Tensor psums, slab;
-        float* slab_ptr = nullptr;
-        int m_tiles = 0;
+        const long add_img = addend_stride == 2 ? ((H + 1) / 2) * ((W + 1) / 2) * C * 2 : dx_img;
+        const uint8_t* bmask = nullptr;
         if (bnr) {
             check_nhwc_bf16(*bn_x, "bn_x");
             TORCH_CHECK(bn_x->sizes().vec() == x_shape, "bn_x must have the shape of dx");
@@ -278,14 +314,38 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
             TORCH_CHECK(bn_mean.has_value() && bn_invstd.has_value(), "bn_mean / bn_invstd missing");
             check_vec_f32(*bn_mean, C, "bn_mean"); check_vec_f32(*bn_invstd, C, "bn_invstd");
             g.bnr_x = bn_x->data_ptr();
-            g.bnr_mask = bn_mask->data_ptr<uint8_t>();
+            bmask = bn_mask->data_ptr<uint8_t>();
+            g.bnr_mask = bmask;
             g.bnr_mean = bn_mean->data_ptr<float>();
             g.bnr_invstd = bn_invstd->data_ptr<float>();
-            m_tiles = conv_igemm_m_tiles(g, nullptr, (int)cfg);
+        }
+        std::vector<int> tiles;
+        int m_tiles = 0;
+        for (long b0 = 0; b0 < B; b0 += per) {
+            g.B = (int)std::min(per, B - b0);
+            tiles.push_back(conv_igemm_m_tiles(g, nullptr, (int)cfg));
+            m_tiles += tiles.back();
+        }
+        Tensor psums, slab;
+        float* slab_ptr = nullptr;
+        if (bnr) {
             slab = at::empty({m_tiles, 2 * C}, dy.options().dtype(at::kFloat));
             slab_ptr = slab.data_ptr<float>();
         }
-        launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, slab_ptr, s, (int)cfg);
+        long row = 0, ci = 0;
+        for (long b0 = 0; b0 < B; b0 += per, ++ci) {
+            ConvGeom gc = g;
+            gc.B = (int)std::min(per, B - b0);
+            gc.addend = at_image(addend_ptr, b0, add_img);
+            gc.addend_mask = reinterpret_cast<const uint8_t*>(at_image(addend_mask_ptr, b0, dx_img / 16));
+            if (bnr) {
+                gc.bnr_x = at_image(bn_x->data_ptr(), b0, dx_img);
+                gc.bnr_mask = reinterpret_cast<const uint8_t*>(at_image(bmask, b0, dx_img / 16));
+            }
+            launch_conv_igemm(at_image(dy.data_ptr(), b0, dy_img), wt.data_ptr(), at_image(dx.data_ptr(), b0, dx_img), gc,
+                              slab_ptr ? slab_ptr + row * 2 * C : nullptr, s, (int)cfg);
+            row += tiles[ci];
+        }
         if (bnr) psums = shrink_rows(slab, m_tiles, 2 * C, kReduceChunks).view({-1, 2, C});
         return {dx, psums};
     }
@@ -314,8 +374,13 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
         }
     Tensor dx = empty_nhwc(B, C, H, W, dy);  // (at::zeros would drop the channels_last request)
     if (need_zero) dx.zero_();
-    TORCH_CHECK((long)dx.numel() * 2 < (1L << 31), "dx exceeds 2 GiB");
-    for (const auto& g : launches) launch_conv_igemm(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), g, nullptr, s, (int)cfg);
+    for (long b0 = 0; b0 < B; b0 += per)
+        for (const auto& g : launches) {
+            ConvGeom gc = g;
+            gc.B = (int)std::min(per, B - b0);
+            launch_conv_igemm(at_image(dy.data_ptr(), b0, dy_img), wt.data_ptr(), at_image(dx.data_ptr(), b0, dx_img), gc,
+                              nullptr, s, (int)cfg);
+        }
     return {dx, Tensor()};
 }
 
@@ -339,31 +404,62 @@ Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, i
     TORCH_CHECK(dy.size(0) == B, "batch mismatch");
     TORCH_CHECK(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1, "wgrad geometry mismatch");
     TORCH_CHECK(C % 64 == 0 && N % 64 == 0, "conv2d_wgrad: channels must be multiples of 64");
-    TORCH_CHECK((long)B * Ho * Wo < (1L << 31), "too many output pixels");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
-    const long wsize_all = N * KH * KW * C;
+    const long wsize = N * KH * KW * C;
+    const long x_img = H * W * C * 2, dy_img = Ho * Wo * N * 2;
+    const long per = chunk_images(B, std::max(x_img, dy_img));
+    const long nchunks = (B + per - 1) / per;
+    TORCH_CHECK(per * Ho * Wo < (1L << 31), "too many output pixels per launch");
+    // every batch chunk is a group of split-K rows of the same slab; one reduction over all of them
+    auto finish = [&](const Tensor& slab, long rows) {
+        Tensor flat = rows == 1 ? slab.view({wsize}) : reduce_slab(slab, (int)rows, wsize);
+        return flat.view({N, KH, KW, C}).permute({0, 3, 1, 2});  // physical [N][KH][KW][C] == channels_last [N,C,KH,KW]
+    };
     if (KH == 3 && KW == 3 && wgrad_win_enabled()) {  // all nine taps per workgroup from one staged window
-        WinGeom wg{(int)B, (int)Ho, (int)Wo, (int)N, (int)H, (int)W, (int)C, (int)C, 3, 3,
-                   (int)stride, (int)stride, (int)pad, (int)pad, 0, 0, 0};
-        if (wgrad_win_plan(wg)) {
-            Tensor slab = at::empty({wg.splits, wsize_all}, x.options().dtype(at::kFloat));
-            launch_wgrad_win(dy.data_ptr(), x.data_ptr(), slab.data_ptr<float>(), wg, cur_stream(x));
-            Tensor flat = wg.splits == 1 ? slab.view({wsize_all}) : reduce_slab(slab, wg.splits, wsize_all);
-            return flat.view({N, KH, KW, C}).permute({0, 3, 1, 2});
+        std::vector<WinGeom> plans;
+        long rows = 0;
+        bool ok = true;
+        for (long b0 = 0; b0 < B && ok; b0 += per) {
+            WinGeom wg{(int)std::min(per, B - b0), (int)Ho, (int)Wo, (int)N, (int)H, (int)W, (int)C, (int)C, 3, 3,
+                       (int)stride, (int)stride, (int)pad, (int)pad, 0, 0, 0};
+            ok = wgrad_win_plan(wg);
+            plans.push_back(wg);
+            rows += wg.splits;
+        }
+        if (ok) {
+            Tensor slab = at::empty({rows, wsize}, x.options().dtype(at::kFloat));
+            long row = 0, ci = 0;
+            for (long b0 = 0; b0 < B; b0 += per, ++ci) {
+                launch_wgrad_win(at_image(dy.data_ptr(), b0, dy_img), at_image(x.data_ptr(), b0, x_img),
+                                 slab.data_ptr<float>() + row * wsize, plans[ci], cur_stream(x));
+                row += plans[ci].splits;
+            }
+            return finish(slab, rows);
         }
     }
-    WgradGeom g{(int)B, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, (int)N, (int)KH, (int)KW, (int)stride, (int)pad, 1};
-    g.splits = conv_wgrad_splits(g);
-    if (splits > 0) {  // explicit split-K factor (tests force the multi-split slab path on small shapes)
-        const long max_splits = std::max<long>(1, (B * Ho * Wo + 31) / 32);
-        g.splits = (int)std::min<long>(std::min<long>(splits, 512), max_splits);
+    std::vector<WgradGeom> geoms;
+    long rows = 0;
+    for (long b0 = 0; b0 < B; b0 += per) {
+        const long nb = std::min(per, B - b0);
+        WgradGeom g{(int)nb, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, (int)N, (int)KH, (int)KW, (int)stride, (int)pad, 1};
+        g.splits = conv_wgrad_splits(g);
+        if (splits > 0) {  // explicit split-K factor (tests force the multi-split slab path on small shapes)
+            const long max_splits = std::max<long>(1, (nb * Ho * Wo + 31) / 32);
+            g.splits = (int)std::min<long>(std::min<long>(splits, 512), max_splits);
+        } else if (nchunks > 1) {
+            g.splits = std::max<int>(1, (int)((g.splits + nchunks - 1) / nchunks));  // the chunks run back to back
+        }
+        geoms.push_back(g);
+        rows += g.splits;
     }
-    const long wsize = N * KH * KW * C;
-    Tensor slab = at::empty({g.splits, wsize}, x.options().dtype(at::kFloat));
-    launch_conv_wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr<float>(), g, cur_stream(x));
-    Tensor flat = g.splits == 1 ? slab.view({wsize}) : reduce_slab(slab, g.splits, wsize);
-    // physical [N][KH][KW][C] == logical [N,C,KH,KW] in channels_last
-    return flat.view({N, KH, KW, C}).permute({0, 3, 1, 2});
+    Tensor slab = at::empty({rows, wsize}, x.options().dtype(at::kFloat));
+    long row = 0, ci = 0;
+    for (long b0 = 0; b0 < B; b0 += per, ++ci) {
+        launch_conv_wgrad(at_image(dy.data_ptr(), b0, dy_img), at_image(x.data_ptr(), b0, x_img),
+                          slab.data_ptr<float>() + row * wsize, geoms[ci], cur_stream(x));
+        row += geoms[ci].splits;
+    }
+    return finish(slab, rows);
 }
 
 // ---- 3-channel stem: 7x7 / stride 2 / pad 3 on the packed image (conv_stem.hip) ---------------------
@@ -376,12 +472,10 @@ std::tuple<Tensor, Tensor, Tensor> conv_stem_fwd(const Tensor& x, const Tensor& 
     TORCH_CHECK(N % 64 == 0, "conv_stem_fwd: Cout must be a multiple of 64");
     TORCH_CHECK(H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2, "conv_stem_fwd: even input size expected");
     const long Hp = H + 6, Wp = W + 8, Ho = H / 2, Wo = W / 2;
-    TORCH_CHECK(B * Hp * Wp * 8 < (1L << 31) && B * Ho * Wo * N * 2 < (1L << 31), "stem tensors exceed 2 GiB");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     hipStream_t s = cur_stream(x);
     Tensor xp = at::empty({B, Hp, Wp, 4}, x.options().memory_format(at::MemoryFormat::Contiguous));
     Tensor wp = at::empty({N, 7, 32}, x.options().memory_format(at::MemoryFormat::Contiguous));
-    launch_stem_pack_x(x.data_ptr(), xp.data_ptr(), (int)B, (int)H, (int)W, s);
     launch_stem_pack_w(w.data_ptr(), wp.data_ptr(), (int)N, s);
     Tensor y = empty_nhwc(B, N, Ho, Wo, x);
     ConvGeom g;
@@ -389,14 +483,29 @@ std::tuple<Tensor, Tensor, Tensor> conv_stem_fwd(const Tensor& x, const Tensor& 
     g.B = B; g.Hin = Hp; g.Win = Wp; g.C = 32; g.pix_elems = 4; g.Hout = Ho; g.Wout = Wo; g.N = N;
     g.nOH = Ho; g.nOW = Wo; g.os = 1; g.is = 2; g.ntaps = 7; g.wtaps = 7;
     for (int t = 0; t < 7; ++t) g.set_tap(t, t, 0, t);
+    const long x_img = H * W * 3 * 2, xp_img = Hp * Wp * 8, y_img = Ho * Wo * N * 2;
+    const long per = chunk_images(B, std::max(xp_img, y_img));
+    std::vector<int> tiles;
+    int m_tiles = 0;
+    for (long b0 = 0; b0 < B; b0 += per) {
+        g.B = (int)std::min(per, B - b0);
+        tiles.push_back(conv_igemm_m_tiles(g, nullptr));
+        m_tiles += tiles.back();
+    }
     Tensor stats, slab;
     float* slab_ptr = nullptr;
-    const int m_tiles = conv_igemm_m_tiles(g, nullptr);
     if (want_stats) {
         slab = at::empty({m_tiles, 2 * N}, x.options().dtype(at::kFloat));
         slab_ptr = slab.data_ptr<float>();
     }
-    launch_conv_igemm(xp.data_ptr(), wp.data_ptr(), y.data_ptr(), g, slab_ptr, s);
+    long row = 0, ci = 0;
+    for (long b0 = 0; b0 < B; b0 += per, ++ci) {
+        g.B = (int)std::min(per, B - b0);
+        launch_stem_pack_x(at_image(x.data_ptr(), b0, x_img), at_image(xp.data_ptr(), b0, xp_img), g.B, (int)H, (int)W, s);
+        launch_conv_igemm(at_image(xp.data_ptr(), b0, xp_img), wp.data_ptr(), at_image(y.data_ptr(), b0, y_img), g,
+                          slab_ptr ? slab_ptr + row * 2 * N : nullptr, s);
+        row += tiles[ci];
+    }
     if (want_stats) stats = shrink_rows(slab, m_tiles, 2 * N, kMaxFinalizeRows).view({-1, 2, N});
     return {y, stats, xp};
 }
@@ -405,10 +514,13 @@ Tensor stem_pack_x(const Tensor& x) {
     check_nhwc_bf16(x, "x");
     const long B = x.size(0), H = x.size(2), W = x.size(3);
     TORCH_CHECK(x.size(1) == 3 && H % 2 == 0 && W % 2 == 0, "stem_pack_x: [B,3,H,W] with even H, W");
-    TORCH_CHECK(B * (H + 6) * (W + 8) * 8 < (1L << 31), "packed stem input exceeds 2 GiB");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor xp = at::empty({B, H + 6, W + 8, 4}, x.options().memory_format(at::MemoryFormat::Contiguous));
-    launch_stem_pack_x(x.data_ptr(), xp.data_ptr(), (int)B, (int)H, (int)W, cur_stream(x));
+    const long x_img = H * W * 3 * 2, xp_img = (H + 6) * (W + 8) * 8;
+    const long per = chunk_images(B, xp_img);
+    for (long b0 = 0; b0 < B; b0 += per)
+        launch_stem_pack_x(at_image(x.data_ptr(), b0, x_img), at_image(xp.data_ptr(), b0, xp_img),
+                           (int)std::min(per, B - b0), (int)H, (int)W, cur_stream(x));
     return xp;
 }
 
@@ -421,12 +533,25 @@ Tensor conv_stem_wgrad(const Tensor& dy, const Tensor& xp) {
     const long Hp = xp.size(1), Wp = xp.size(2);
     TORCH_CHECK(xp.size(0) == B && Hp == 2 * Ho + 6 && Wp == 2 * Wo + 8 && N % 64 == 0, "conv_stem_wgrad: shape mismatch");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dy.device());
-    WinGeom g{(int)B, (int)Ho, (int)Wo, (int)N, (int)Hp, (int)(Wp / 2), 8, 32, 7, 1, 2, 1, 0, 0, 1, 0, 0};
-    TORCH_CHECK(wgrad_win_plan(g), "conv_stem_wgrad: output rows of ", Wo, " pixels do not fit the window kernel");
     const long wsize = N * 147;
-    Tensor slab = at::empty({g.splits, wsize}, dy.options().dtype(at::kFloat));
-    launch_wgrad_win(dy.data_ptr(), xp.data_ptr(), slab.data_ptr<float>(), g, cur_stream(dy));
-    Tensor flat = g.splits == 1 ? slab.view({wsize}) : reduce_slab(slab, g.splits, wsize);
+    const long dy_img = Ho * Wo * N * 2, xp_img = Hp * Wp * 8;
+    const long per = chunk_images(B, std::max(dy_img, xp_img));
+    std::vector<WinGeom> plans;
+    long rows = 0;
+    for (long b0 = 0; b0 < B; b0 += per) {
+        WinGeom g{(int)std::min(per, B - b0), (int)Ho, (int)Wo, (int)N, (int)Hp, (int)(Wp / 2), 8, 32, 7, 1, 2, 1, 0, 0, 1, 0, 0};
+        TORCH_CHECK(wgrad_win_plan(g), "conv_stem_wgrad: output rows of ", Wo, " pixels do not fit the window kernel");
+        plans.push_back(g);
+        rows += g.splits;
+    }
+    Tensor slab = at::empty({rows, wsize}, dy.options().dtype(at::kFloat));
+    long row = 0, ci = 0;
+    for (long b0 = 0; b0 < B; b0 += per, ++ci) {
+        launch_wgrad_win(at_image(dy.data_ptr(), b0, dy_img), at_image(xp.data_ptr(), b0, xp_img),
+                         slab.data_ptr<float>() + row * wsize, plans[ci], cur_stream(dy));
+        row += plans[ci].splits;
+    }
+    Tensor flat = rows == 1 ? slab.view({wsize}) : reduce_slab(slab, (int)rows, wsize);
     return flat.view({N, 7, 7, 3}).permute({0, 3, 1, 2});
 }
 
@@ -730,7 +855,12 @@ std::tuple<Tensor, Tensor> maxpool3x3s2_fwd(const Tensor& x) {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor y = empty_nhwc(B, C, Ho, Wo, x);
     Tensor arg = at::empty({B, Ho, Wo, C}, x.options().dtype(at::kByte));
-    launch_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), arg.data_ptr<uint8_t>(), B, H, W, C, Ho, Wo, cur_stream(x));
+    const long x_img = H * W * C * 2, y_img = Ho * Wo * C * 2;
+    const long per = chunk_images(B, x_img);
+    for (long b0 = 0; b0 < B; b0 += per)
+        launch_maxpool3x3s2_fwd(at_image(x.data_ptr(), b0, x_img), at_image(y.data_ptr(), b0, y_img),
+                                reinterpret_cast<uint8_t*>(at_image(arg.data_ptr(), b0, y_img / 2)),
+                                std::min(per, B - b0), H, W, C, Ho, Wo, cur_stream(x));
     return {y, arg};
 }
 Tensor maxpool3x3s2_bwd(const Tensor& dy, const Tensor& arg, std::vector<int64_t> x_shape) {
@@ -742,7 +872,12 @@ Tensor maxpool3x3s2_bwd(const Tensor& dy, const Tensor& arg, std::vector<int64_t
                 "argmax tensor mismatch");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dy.device());
     Tensor dx = empty_nhwc(B, C, H, W, dy);
-    launch_maxpool3x3s2_bwd(dy.data_ptr(), arg.data_ptr<uint8_t>(), dx.data_ptr(), B, H, W, C, Ho, Wo, cur_stream(dy));
+    const long x_img = H * W * C * 2, y_img = Ho * Wo * C * 2;
+    const long per = chunk_images(B, x_img);
+    for (long b0 = 0; b0 < B; b0 += per)
+        launch_maxpool3x3s2_bwd(at_image(dy.data_ptr(), b0, y_img),
+                                reinterpret_cast<const uint8_t*>(at_image(arg.data_ptr(), b0, y_img / 2)),
+                                at_image(dx.data_ptr(), b0, x_img), std::min(per, B - b0), H, W, C, Ho, Wo, cur_stream(dy));
     return dx;
 }
 // ---- stem tail fused: maxpool3x3/2/1(relu(bn(u))) --------------------------------------------------------
@@ -758,9 +893,14 @@ std::tuple<Tensor, Tensor, Tensor> bn_relu_maxpool_fwd(const Tensor& u, const Te
     Tensor y = empty_nhwc(B, C, Ho, Wo, u);
     Tensor arg = at::empty({B, Ho, Wo, C}, u.options().dtype(at::kByte));
     Tensor mask = at::empty({B * H * W, C / 8}, u.options().dtype(at::kByte));
-    launch_bn_relu_maxpool_fwd(u.data_ptr(), y.data_ptr(), arg.data_ptr<uint8_t>(), mask.data_ptr<uint8_t>(), B, H, W, C, Ho, Wo,
-                               mean.data_ptr<float>(), invstd.data_ptr<float>(), gamma.data_ptr<float>(),
-                               beta.data_ptr<float>(), cur_stream(u));
+    const long u_img = H * W * C * 2, y_img = Ho * Wo * C * 2;
+    const long per = chunk_images(B, u_img);
+    for (long b0 = 0; b0 < B; b0 += per)
+        launch_bn_relu_maxpool_fwd(at_image(u.data_ptr(), b0, u_img), at_image(y.data_ptr(), b0, y_img),
+                                   reinterpret_cast<uint8_t*>(at_image(arg.data_ptr(), b0, y_img / 2)),
+                                   reinterpret_cast<uint8_t*>(at_image(mask.data_ptr(), b0, u_img / 16)),
+                                   std::min(per, B - b0), H, W, C, Ho, Wo, mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                                   gamma.data_ptr<float>(), beta.data_ptr<float>(), cur_stream(u));
     return {y, arg, mask};
 }
 
@@ -1171,6 +1311,8 @@ void bind_ops(pybind11::module& m) {
     m.def("layernorm_fwd", &layernorm_fwd);
     m.def("layernorm_bwd", &layernorm_bwd, pybind11::arg("dy"), pybind11::arg("x"), pybind11::arg("mean"),
           pybind11::arg("rstd"), pybind11::arg("gamma"), pybind11::arg("addend") = pybind11::none());
+    m.def("set_activation_window", &set_activation_window,
+          "bytes of one operand a convolution / pooling launch may span (tests shrink it to force batch chunking)");
     m.def("maxpool3x3s2_fwd", &maxpool3x3s2_fwd);
     m.def("maxpool3x3s2_bwd", &maxpool3x3s2_bwd);
     m.def("bn_relu_maxpool_fwd", &bn_relu_maxpool_fwd);

@@ -30,15 +30,14 @@ def conv_unsupported_reason(x, w, stride: int, padding: int):
     if _is_stem(w, stride, padding):
         if x.shape[2] % 2 or x.shape[3] % 2 or x.shape[3] // 2 > 112 or cout % 64:
             return f"stem input {tuple(x.shape)}"
-        if x.shape[0] * (x.shape[2] + 6) * (x.shape[3] + 8) * 8 >= (1 << 31) or x.shape[0] * x.shape[2] * x.shape[3] * cout // 2 >= (1 << 31):
-            return "activation >= 2 GiB"
         return None
     if cin % 64 or cout % 64:
         return f"channels {cin}->{cout} not multiples of 64"
     if kh * kw > 49 or stride not in (1, 2):
         return f"kernel {kh}x{kw} stride {stride}"
-    if x.numel() * 2 >= (1 << 31):
-        return "activation >= 2 GiB"
+    # (activations of any size: the bindings cut the batch into chunks that fit one buffer descriptor)
+    if x.numel() // max(x.shape[0], 1) * 2 * max(cout // max(cin, 1), 1) >= (1 << 31):
+        return "one image >= 2 GiB"
     return None
 
 
@@ -48,8 +47,6 @@ def bn_unsupported_reason(x):
     c = x.shape[1]
     if c % 8 or c // 8 > 256 or 256 % (c // 8):
         return f"channel count {c}"
-    if x.numel() * 2 >= (1 << 31):
-        return "activation >= 2 GiB"
     return None
 
 

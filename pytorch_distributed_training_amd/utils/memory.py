@@ -3,16 +3,19 @@
 One ``gpurun`` round trip costs minutes and an out-of-memory kill can take the box down, so the batch is
 chosen from a model instead of by trial and error: two short probe steps give the activation bytes per image
 (the slope of peak memory in the batch) and the fixed cost (weights, optimizer state, buckets, workspaces),
-forward hooks give the largest single activation per image, and the batch is the largest that fits both
+forward hooks give the largest single activation per image, and the batch is the largest that fits ``fraction``
+of the device memory.
 
-* ``fraction`` of the device memory, and
-* the 2 GiB-per-tensor range of the buffer descriptors the HIP kernels address activations with.
+The buffer descriptors the convolution / pooling kernels address an operand with span 2 GiB per LAUNCH, not per
+tensor: the bindings cut a larger batch into chunks of images (csrc/binding/ops.cpp ``chunk_images``), so the
+descriptor range only requires that ONE image of the widest activation fits (``by_tensor_range`` is reported as
+the images per launch of that activation: below it a layer runs as one launch, above it as several).
 """
 from __future__ import annotations
 
 import torch
 
-_TENSOR_LIMIT = (1 << 31) - 1  # bytes one activation tensor may span (32-bit buffer offsets)
+_TENSOR_LIMIT = (1 << 31) - 4096  # bytes of one operand a single launch may span (32-bit buffer offsets)
 
 
 def _probe_step(engine, batch: int, image_shape, num_classes: int):
@@ -57,7 +60,9 @@ def suggest_batch(engine, image_shape, num_classes: int, probe: int = 16, fracti
     # the packed stem image is the widest per-image tensor some networks make: (H+6) x (W+8) x 4 elements
     widest = max(biggest["numel"], (image_shape[-2] + 6) * (image_shape[-1] + 8) * 4 if len(image_shape) == 3 else 0)
     by_tensor = _TENSOR_LIMIT // max(1, widest * elem)
-    pick = min(by_memory, by_tensor)
+    if by_tensor < 1:
+        raise RuntimeError(f"one image of the widest activation ({widest * elem} bytes) exceeds a buffer descriptor")
+    pick = by_memory
     if cap is not None:
         pick = min(pick, cap)
     pick = max(multiple, pick // multiple * multiple) if pick >= multiple else max(1, pick)
