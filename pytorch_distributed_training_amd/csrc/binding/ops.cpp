@@ -628,14 +628,25 @@ const float* count_ptr(const c10::optional<Tensor>& count_dev) {
 }
 
 // stats: partial rows [P,2,C]
-std::tuple<Tensor, Tensor> bn_finalize(const Tensor& stats, double count, const c10::optional<Tensor>& count_dev,
-                                       double eps, double momentum, const c10::optional<Tensor>& running_mean,
-                                       const c10::optional<Tensor>& running_var,
-                                       const c10::optional<Tensor>& num_batches_tracked) {
+// ipc (SyncBatchNorm, world > 1): the kernel exchanges the statistics with the peers over the IPC mailboxes itself;
+// the third result is then the global element count (1-element fp32 tensor) the backward kernels divide by
+std::tuple<Tensor, Tensor, Tensor> bn_finalize(const Tensor& stats, double count, const c10::optional<Tensor>& count_dev,
+                                               double eps, double momentum, const c10::optional<Tensor>& running_mean,
+                                               const c10::optional<Tensor>& running_var,
+                                               const c10::optional<Tensor>& num_batches_tracked,
+                                               const std::shared_ptr<IpcAllReduce>& ipc) {
     check_partials(stats, "stats");
     const long P = stats.size(0), C = stats.size(2);
     c10::hip::HIPGuardMasqueradingAsCUDA guard(stats.device());
     Tensor mean = at::empty({C}, stats.options()), invstd = at::empty({C}, stats.options());
+    Tensor count_total;
+    const IpcMailboxes* mb = nullptr;
+    if (ipc && ipc->world_size() > 1) {
+        TORCH_CHECK(count >= 1.0 && count < 4294967296.0 && !(count_dev.has_value() && count_dev->defined()),
+                    "bn_finalize: the exchanged count is this rank's host-side element count");
+        mb = &ipc->mailboxes_for(3 * C + 1);
+        count_total = at::empty({1}, stats.options());
+    }
     float *rm = nullptr, *rv = nullptr;
     if (running_mean.has_value() && running_mean->defined()) {
         check_vec_f32(*running_mean, C, "running_mean");
@@ -650,10 +661,10 @@ std::tuple<Tensor, Tensor> bn_finalize(const Tensor& stats, double count, const 
                     "num_batches_tracked: expected a 1-element int64 GPU tensor");
         nbt = reinterpret_cast<long*>(num_batches_tracked->data_ptr<int64_t>());
     }
-    launch_bn_finalize(stats.data_ptr<float>(), (int)P, (int)C, (float)count, count_ptr(count_dev), (float)eps,
+    launch_bn_finalize(stats.data_ptr<float>(), (int)P, (int)C, count, count_ptr(count_dev), (float)eps,
                        (float)momentum, rm, rv, nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(), nullptr,
-                       cur_stream(stats));
-    return {mean, invstd};
+                       cur_stream(stats), mb, mb ? count_total.data_ptr<float>() : nullptr);
+    return {mean, invstd, count_total};
 }
 
 // partial rows [P,2,C] -> [2,C] (SyncBN needs the local sums before the all-reduce)
@@ -731,7 +742,8 @@ Tensor bn_bwd_reduce(const Tensor& dz, const c10::optional<Tensor>& z, const Ten
 std::tuple<Tensor, Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::optional<Tensor>& z, const Tensor& x,
                                                 const Tensor& mean, const Tensor& invstd, const Tensor& gamma,
                                                 const Tensor& psums, double count,
-                                                const c10::optional<Tensor>& count_dev, bool relu, bool want_dres) {
+                                                const c10::optional<Tensor>& count_dev, bool relu, bool want_dres,
+                                                const std::shared_ptr<IpcAllReduce>& ipc) {
     check_nhwc_bf16(dz, "dz"); check_nhwc_bf16(x, "x");
     TORCH_CHECK(dz.sizes() == x.sizes(), "dz/x shape mismatch");
     const long C = x.size(1), M = x.numel() / C;
@@ -756,7 +768,8 @@ std::tuple<Tensor, Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::opt
     launch_bn_bwd_elemt(dz.data_ptr(), zp, x.data_ptr(), dx.data_ptr(), drp, M, (int)C, mean.data_ptr<float>(),
                         invstd.data_ptr<float>(), gamma.data_ptr<float>(), psums.data_ptr<float>(), (int)psums.size(0),
                         sums.data_ptr<float>(), (float)count, count_ptr(count_dev), relu ? 1 : 0,
-                        coef.data_ptr<float>(), cur_stream(x));
+                        coef.data_ptr<float>(), cur_stream(x),
+                        ipc && ipc->world_size() > 1 ? &ipc->mailboxes_for(2 * C) : nullptr);
     return {dx, dres, sums};
 }
 

@@ -37,8 +37,9 @@ IpcAllReduce::IpcAllReduce(int rank, int world, int device, int cap_elems, doubl
     PDT_HIP(hipMemset(base, 0, bytes_));
     for (auto& m : mb_.mail) m = nullptr;
     mb_.mail[rank] = static_cast<uint64_t*>(base);
-    PDT_HIP(hipMalloc(reinterpret_cast<void**>(&mb_.seq), sizeof(uint32_t)));
-    PDT_HIP(hipMemset(mb_.seq, 0, sizeof(uint32_t)));
+    PDT_HIP(hipMalloc(reinterpret_cast<void**>(&mb_.seq), 2 * sizeof(uint32_t)));
+    PDT_HIP(hipMemset(mb_.seq, 0, 2 * sizeof(uint32_t)));
+    mb_.done = mb_.seq + 1;
     void* hs = nullptr;
     PDT_HIP(hipHostMalloc(&hs, sizeof(uint32_t), hipHostMallocMapped));
     host_status_ = static_cast<volatile uint32_t*>(hs);
@@ -83,6 +84,13 @@ void IpcAllReduce::open_peers(const std::vector<std::string>& h) {
 
 void IpcAllReduce::clear_error() {
     if (host_status_) *host_status_ = 0;
+}
+
+const IpcMailboxes& IpcAllReduce::mailboxes_for(int64_t n) {
+    TORCH_CHECK(ready_, "IpcAllReduce: open_peers() has not run");
+    TORCH_CHECK(n >= 0 && n <= mb_.cap, "IpcAllReduce: ", n, " elements exceed the mailbox capacity ", mb_.cap);
+    TORCH_CHECK(!timed_out(), "IpcAllReduce: an earlier exchange ran out of time waiting for a peer");
+    return mb_;
 }
 
 void IpcAllReduce::all_reduce(float* data, int64_t n, hipStream_t s) {

@@ -35,6 +35,7 @@ struct IpcMailboxes {
     int rank, world;
     int cap;                  // elements per slot
     uint32_t* seq;            // device word: sequence number of the last finished operation
+    uint32_t* done;           // device word: blocks of the running multi-block operation that have finished
     uint32_t* status;         // host-pinned word: set to 1 by a wait that ran out of time
     long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
 };
@@ -58,6 +59,8 @@ class IpcAllReduce {
     void clear_error();
     void set_timeout(double seconds) { mb_.timeout_ticks = (long long)(seconds * 100e6); }
     void all_reduce(float* data, int64_t n, hipStream_t s);
+    // for kernels that do the exchange themselves (ipc_device.h): the mailboxes, after the same checks as above
+    const IpcMailboxes& mailboxes_for(int64_t n_elems);
 
    private:
     int device_;

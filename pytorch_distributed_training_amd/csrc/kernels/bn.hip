@@ -13,12 +13,14 @@
 #include <cstdlib>
 #include "common.h"
 #include "kernels.h"
+#include "../comm/ipc_device.h"
 
 namespace pdt {
 namespace {
 
 constexpr int kThreads = 256;
 constexpr long kElemtTableBlocks = 4096;  // bwd_elemt: above this many chunks the coefficient table pays
+constexpr long kSyncPrologueBlocks = 32;  // SyncBN: largest grid whose blocks exchange the sums in their prologue
 constexpr int kUnroll = 4;  // rows per thread and trip in the streaming kernels (bn_apply+res: 1: 5.3, 2: 5.9, 4: 5.8, 8: 5.6 TB/s; 2 vs 4 is a wash end to end)
 
 struct Map {
@@ -97,13 +99,24 @@ __global__ __launch_bounds__(kThreads) void k_bn_stats(const bf16* __restrict__ 
 // channels: the partial rows are summed here (fixed order -> deterministic), so no separate
 // reduction launch sits between the conv and the normalisation.  Thread 0 also bumps
 // num_batches_tracked: one launch does everything the reference needs 3 kernels + a host add for.
+//
+// SyncBatchNorm (mb.world > 1): the kernel also does the exchange between the ranks (comm/ipc_device.h), in place
+// of a packed tensor, an all-reduce launch and the kernels around them.  Each rank turns its sums into
+// (count, mean, M2 = sum (x - mean)^2), pushes them into every peer's mailbox, polls its own and merges the W
+// triples in rank order with the pairwise update of Chan et al. (what torch's batch_norm_gather_stats_with_counts
+// does with Welford's): no E[x^2] - E[x]^2 over the global batch, identical bits on every rank.  The mean travels
+// as two floats (hi + lo), the count as an integer.  Message layout: [mean hi (C)][mean lo (C)][M2 (C)][count].
 __global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restrict__ stats, int nparts, int C,
-                                                          float count, const float* __restrict__ count_dev, float eps,
+                                                          double count, const float* __restrict__ count_dev, float eps,
                                                           float momentum, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var,
                                                           long* __restrict__ num_batches_tracked,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
-                                                          float* __restrict__ sums_out) {
+                                                          float* __restrict__ sums_out, const IpcMailboxes mb,
+                                                          float* __restrict__ count_out) {
+    const bool exchange = mb.world > 1 && mean != nullptr;
+    const uint32_t seq = exchange ? ipc_begin(mb) : 0u;
+    bool late = false;
     // The partial rows are summed in DOUBLE and the variance is formed in double: E[x^2] - E[x]^2 cancels
     // catastrophically in fp32 once |mean| >> std (a million fp32 additions lose ~1e-6 of sum(x^2), which is
     // (mean/std)^2 * 1e-6 of the variance).  With double here the only fp32 rounding left is inside one tile's
@@ -148,10 +161,36 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restric
             sums_out[C + c] = (float)q;
         }
         if (mean) {
-            const double n = (double)(count_dev ? count_dev[0] : count);
-            const double mu = s / n;
+            double n = count_dev ? (double)count_dev[0] : count;
+            double mu = s / n;
             double var = q / n - mu * mu;
             if (var < 0.0) var = 0.0;  // (NaN compares false: it is kept)
+            if (exchange) {
+                const float hi = (float)mu;
+                ipc_push(mb, seq, c, hi);
+                ipc_push(mb, seq, C + c, (float)(mu - (double)hi));
+                ipc_push(mb, seq, 2 * C + c, (float)(var * n));
+                if (c == 0) ipc_push_bits(mb, seq, 3 * C, (uint32_t)(n + 0.5));
+                const long long t0 = wall_clock64();
+                double nt = 0.0, wsum = 0.0;
+                for (int r = 0; r < mb.world; ++r) {
+                    const double nr = (double)ipc_wait_bits(mb, seq, r, 3 * C, &late, t0);
+                    const double mr = (double)ipc_wait(mb, seq, r, c, &late, t0) + (double)ipc_wait(mb, seq, r, C + c, &late, t0);
+                    nt += nr;
+                    wsum += nr * mr;
+                }
+                const double gm = wsum / nt;
+                double m2 = 0.0;
+                for (int r = 0; r < mb.world; ++r) {  // (the words have arrived: these reads return at once)
+                    const double nr = (double)ipc_wait_bits(mb, seq, r, 3 * C, &late, t0);
+                    const double mr = (double)ipc_wait(mb, seq, r, c, &late, t0) + (double)ipc_wait(mb, seq, r, C + c, &late, t0);
+                    m2 += (double)ipc_wait(mb, seq, r, 2 * C + c, &late, t0) + nr * (mr - gm) * (mr - gm);
+                }
+                n = nt;
+                mu = gm;
+                var = m2 / nt;
+                if (c == 0 && count_out) count_out[0] = (float)nt;
+            }
             mean[c] = (float)mu;
             invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
             if (running_mean) {
@@ -162,6 +201,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restric
         }
     }
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
+    if (exchange) ipc_end(mb, seq, late);
 }
 
 // With RELU the kernel also writes one bit per element (uint8 per 8 channels): backward reads this
@@ -302,11 +342,17 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_coef(const float* __restric
                                                           const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, float count,
                                                           const float* __restrict__ count_dev,
-                                                          float* __restrict__ sums_out, float* __restrict__ coef) {
+                                                          float* __restrict__ sums_out, float* __restrict__ coef,
+                                                          const IpcMailboxes mb) {
     // 32 channels per block, 8 lanes per channel over the partial rows (fixed order -> deterministic)
+    // SyncBatchNorm (mb.world > 1): sums_out keeps the LOCAL sums (the affine gradients, averaged by DDP), the
+    // coefficients use the sums over all ranks, exchanged here (message: [sum dz (C)][sum dz*xhat (C)])
     __shared__ float red[8][32][2];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
+    const bool exchange = mb.world > 1;
+    const uint32_t seq = exchange ? ipc_begin(mb) : 0u;
+    bool late = false;
     float sa = 0.f, sb = 0.f;
     if (c < C)
         for (int p = pl; p < nps; p += 8) {
@@ -316,20 +362,33 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_coef(const float* __restric
     red[pl][cl][0] = sa;
     red[pl][cl][1] = sb;
     __syncthreads();
-    if (pl != 0 || c >= C) return;
+    if (pl == 0 && c < C) {
 #pragma unroll
-    for (int r = 1; r < 8; ++r) {
-        sa += red[r][cl][0];
-        sb += red[r][cl][1];
+        for (int r = 1; r < 8; ++r) {
+            sa += red[r][cl][0];
+            sb += red[r][cl][1];
+        }
+        sums_out[c] = sa;
+        sums_out[C + c] = sb;
+        if (exchange) {
+            ipc_push(mb, seq, c, sa);
+            ipc_push(mb, seq, C + c, sb);
+            const long long t0 = wall_clock64();
+            sa = 0.f;
+            sb = 0.f;
+            for (int r = 0; r < mb.world; ++r) {
+                sa += ipc_wait(mb, seq, r, c, &late, t0);
+                sb += ipc_wait(mb, seq, r, C + c, &late, t0);
+            }
+        }
+        const float invn = 1.f / (count_dev ? count_dev[0] : count);
+        const float is = invstd[c], g_is = gamma[c] * is;
+        const float c1 = sa * invn, c2 = sb * invn;
+        coef[c] = g_is;
+        coef[C + c] = -g_is * c2 * is;
+        coef[2 * C + c] = g_is * (c2 * is * mean[c] - c1);
     }
-    sums_out[c] = sa;
-    sums_out[C + c] = sb;
-    const float invn = 1.f / (count_dev ? count_dev[0] : count);
-    const float is = invstd[c], g_is = gamma[c] * is;
-    const float c1 = sa * invn, c2 = sb * invn;
-    coef[c] = g_is;
-    coef[C + c] = -g_is * c2 * is;
-    coef[2 * C + c] = g_is * (c2 * is * mean[c] - c1);
+    if (exchange) ipc_end(mb, seq, late);
 }
 
 // dx = k1*dzm + k2*x + k3 with per-channel k's (see host comment); dres = dzm
@@ -343,9 +402,14 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
                                                            const float* __restrict__ psums, int nps,
                                                            float* __restrict__ sums_out, float count,
                                                            const float* __restrict__ count_dev,
-                                                           const float* __restrict__ coef) {
+                                                           const float* __restrict__ coef, const IpcMailboxes mb) {
     const Map m = make_map(C);
     float k1[8], k2[8], k3[8];
+    // SyncBatchNorm on a small tensor (no table kernel in front): block 0 pushes this rank's sums, the first row
+    // lane of EVERY block polls the mailbox for its 8 channels and hands the totals to the block through LDS
+    const bool exchange = mb.world > 1 && coef == nullptr;
+    const uint32_t seq = exchange ? ipc_begin(mb) : 0u;
+    bool late = false;
     if (coef != nullptr) {  // big tensors: k_bn_bwd_coef made the table, a block only streams its one chunk
         ld8f(coef + m.cg * 8, k1);
         ld8f(coef + C + m.cg * 8, k2);
@@ -372,6 +436,35 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
             for (int k = 0; k < 8; ++k) {
                 sums_out[m.cg * 8 + k] = sa[k];
                 sums_out[C + m.cg * 8 + k] = sb[k];
+            }
+        }
+        if (exchange) {
+            __shared__ float tot[2][2048];  // C <= 2048 (bn_channels_ok)
+            if (m.rl == 0) {
+                if (blockIdx.x == 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        ipc_push(mb, seq, m.cg * 8 + k, sa[k]);
+                        ipc_push(mb, seq, C + m.cg * 8 + k, sb[k]);
+                    }
+                }
+                const long long t0 = wall_clock64();
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float ta = 0.f, tb = 0.f;
+                    for (int r = 0; r < mb.world; ++r) {
+                        ta += ipc_wait(mb, seq, r, m.cg * 8 + k, &late, t0);
+                        tb += ipc_wait(mb, seq, r, C + m.cg * 8 + k, &late, t0);
+                    }
+                    tot[0][m.cg * 8 + k] = ta;
+                    tot[1][m.cg * 8 + k] = tb;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sa[k] = tot[0][m.cg * 8 + k];
+                sb[k] = tot[1][m.cg * 8 + k];
             }
         }
 #pragma unroll
@@ -415,6 +508,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
             if (DRES) st8(dres + off, gm);
         }
     }
+    if (exchange) ipc_end(mb, seq, late);
 }
 
 // Grid of the streaming kernels: ONE chunk (kUnroll * R adjacent rows, 16 KiB per tensor) per block, blocks
@@ -557,11 +651,19 @@ void launch_bn_stats(const void* x, long M, int C, float* slab, int parts, hipSt
     hipLaunchKernelGGL(k_bn_stats, dim3(parts), dim3(kThreads), lds, s, (const bf16*)x, M, C, slab);
 }
 
-void launch_bn_finalize(const float* stats, int nparts, int C, float count, const float* count_dev, float eps,
+static IpcMailboxes no_exchange() {
+    IpcMailboxes mb{};
+    mb.world = 1;
+    return mb;
+}
+
+void launch_bn_finalize(const float* stats, int nparts, int C, double count, const float* count_dev, float eps,
                         float momentum, float* running_mean, float* running_var, long* num_batches_tracked,
-                        float* mean, float* invstd, float* sums_out, hipStream_t s) {
+                        float* mean, float* invstd, float* sums_out, hipStream_t s, const IpcMailboxes* mb,
+                        float* count_out) {
     hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(kThreads), 0, s, stats, nparts, C, count, count_dev,
-                       eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd, sums_out);
+                       eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd, sums_out,
+                       mb ? *mb : no_exchange(), count_out);
 }
 
 void launch_bn_apply(const void* x, const void* residual, void* z, uint8_t* mask, long M, int C, const float* mean,
@@ -594,14 +696,20 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, 
 void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx, void* dres, long M, int C,
                          const float* mean, const float* invstd, const float* gamma, const float* psums, int nps,
                          float* sums_out, float count, const float* count_dev, int relu, float* coef,
-                         hipStream_t s) {
+                         hipStream_t s, const IpcMailboxes* mbp) {
+    const IpcMailboxes mb = mbp ? *mbp : no_exchange();
     const int R = kThreads / (C >> 3);
     // small tensors: one launch, <= 2048 blocks each folding the nps partial rows in its prologue;
     // big ones (coef workspace given): table kernel first, then one chunk per block
-    const bool table = coef != nullptr && stream_blocks(M, R, 0) > kElemtTableBlocks;
+    // SyncBatchNorm: the blocks that exchange with the peers WAIT for them.  In the prologue of this kernel that is
+    // every block of the grid, which is fine for a handful of blocks (tiny tensors, where a launch saved matters
+    // most) but a grid that fills the chip with waiting waves would starve a peer that shares the GPU (the one-GPU
+    // rehearsal of W > 1) and burn the chip for nothing elsewhere: larger grids take the table kernel (<= 64 blocks).
+    const bool sync = mb.world > 1;
+    const bool table = coef != nullptr && stream_blocks(M, R, 0) > (sync ? kSyncPrologueBlocks : kElemtTableBlocks);
     if (table)
         hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 31) / 32), dim3(kThreads), 0, s, psums, nps, C,
-                           mean, invstd, gamma, count, count_dev, sums_out, coef);
+                           mean, invstd, gamma, count, count_dev, sums_out, coef, mb);
     else
         coef = nullptr;
     const long blocks = stream_blocks(M, R, table ? 0 : 2048);
@@ -609,7 +717,7 @@ void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx,
 #define PDT_ELEMT(RELU, DRES)                                                                                  \
     hipLaunchKernelGGL((k_bn_bwd_elemt<RELU, DRES>), grid, block, 0, s, (const bf16*)dz, (const uint8_t*)z,       \
                        (const bf16*)x, (bf16*)dx, (bf16*)dres, M, C, mean, invstd, gamma, psums, nps, sums_out, count,   \
-                       count_dev, coef)
+                       count_dev, coef, mb)
     if (relu && dres) PDT_ELEMT(true, true);
     else if (relu) PDT_ELEMT(true, false);
     else if (dres) PDT_ELEMT(false, true);

@@ -1,6 +1,7 @@
 // Host-side launchers of the gfx950 kernels.  Pure HIP (no torch headers): the bindings in
 // csrc/binding validate shapes / dtypes / alignment and pass raw pointers + the current stream.
 #pragma once
+#include "../comm/ipc_allreduce.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -69,9 +70,12 @@ int bn_parts(long M, int C);  // number of partial rows the stats / bwd-reduce k
 void launch_bn_stats(const void* x, long M, int C, float* slab /*[parts][2][C]*/, int parts, hipStream_t s);
 // stats: partial rows [nparts][2][C] (nparts <= 512).  Sums them, writes mean / invstd, updates the
 // running stats and num_batches_tracked (each optional) and optionally the reduced sums [2][C].
-void launch_bn_finalize(const float* stats, int nparts, int C, float count, const float* count_dev, float eps,
+// mb (SyncBatchNorm over IPC mailboxes, world > 1): the kernel exchanges (count, mean, M2) with the peers itself and
+// writes the global count to count_out[0]; null: single-rank statistics
+void launch_bn_finalize(const float* stats, int nparts, int C, double count, const float* count_dev, float eps,
                         float momentum, float* running_mean, float* running_var, long* num_batches_tracked,
-                        float* mean, float* invstd, float* sums_out, hipStream_t s);
+                        float* mean, float* invstd, float* sums_out, hipStream_t s, const IpcMailboxes* mb = nullptr,
+                        float* count_out = nullptr);
 // relu: also writes the 1-bit-per-element activity mask [M][C/8] that the backward kernels take as `z`
 // per-channel BatchNorm coefficients of a tensor that enters another kernel un-normalised (all null: none)
 struct BnAffine {
@@ -94,7 +98,8 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, 
 void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx, void* dres, long M, int C,
                          const float* mean, const float* invstd, const float* gamma, const float* psums /*[nps][2][C]*/,
                          int nps, float* sums_out /*[2][C] or null*/, float count, const float* count_dev, int relu,
-                         float* coef /*[3][C] workspace or null*/, hipStream_t s);
+                         float* coef /*[3][C] workspace or null*/, hipStream_t s,
+                         const IpcMailboxes* mb = nullptr /* SyncBatchNorm: global sums exchanged in the kernel */);
 
 // ---- LayerNorm over the last dim of [M, D] bf16 (layernorm.hip) -----------------------------------
 bool layernorm_dim_ok(int D);

@@ -229,16 +229,43 @@ class _BNSink:
         return ps if ok else None
 
 
+def _inkernel_exchange(be, x, cfg: BNConfig, n_floats: int):
+    """The IPC mailboxes of ``cfg.group`` when the BN kernels can do the SyncBN exchange themselves (native
+    kernels, ranks on one host, message fits), else None (``parallel/ipc.py`` decides once per group)."""
+    if be is reference or not x.is_cuda or os.environ.get("PDT_SYNCBN_INKERNEL", "1") == "0":
+        return None
+    from ..parallel.ipc import small_all_reduce_path
+
+    ipc, _ = small_all_reduce_path(cfg.group, x.device)
+    return ipc if (ipc is not None and n_floats <= ipc.capacity) else None
+
+
 def _bn_moments(be, x, stats, cfg: BNConfig):
-    """Batch (or running) mean / invstd of ``x`` for one BN node -> ``(mean, invstd, count, count_t, world)``.
-    In training with SyncBN the packed ``[sum, sum_sq, count]`` is all-reduced once (no host sync)."""
+    """Batch (or running) mean / invstd of ``x`` for one BN node -> ``(mean, invstd, count, count_t, world, ipc)``.
+    In training with SyncBN the statistics are exchanged INSIDE the finalize kernel over the IPC mailboxes (``ipc``
+    is then what the backward kernels use too); without them the packed ``[sum, sum_sq, count]`` is all-reduced
+    once by the process group (no host sync either way)."""
     world = _sync_world(cfg)
     b, c, h, w = x.shape
     count = float(b * h * w)
     count_t = None
+    ipc = None
     if cfg.training:
         if stats is None:
             stats = be.bn_stats(x)
+        if world > 1:
+            ipc = _inkernel_exchange(be, x, cfg, 3 * c + 1)
+        mom = 0.0
+        if cfg.running_mean is not None:
+            mom = cfg.momentum
+            if mom is None:  # cumulative moving average (host sync, like the stock module)
+                mom = 1.0 / (float(cfg.num_batches_tracked.item()) + 1.0)
+        if ipc is not None:
+            # (count, mean, M2) of every rank merged in rank order by the kernel itself: zero extra launches
+            mean, invstd, count_t = be.bn_finalize_sync(stats, count, cfg.eps, cfg.running_mean, cfg.running_var, mom,
+                                                        cfg.num_batches_tracked if cfg.running_mean is not None else None,
+                                                        ipc.native)
+            return mean, invstd, count, count_t, world, ipc
         if world > 1:
             # [sum(C), sum_sq(C), count]: one all-reduce, counts may differ per rank
             packed = torch.empty(2 * c + 4, dtype=torch.float32, device=x.device)
@@ -248,17 +275,12 @@ def _bn_moments(be, x, stats, cfg: BNConfig):
             stats = packed[: 2 * c].view(1, 2, c)
             count_t = packed[2 * c: 2 * c + 1]
         cnt = count_t if count_t is not None else count
-        mom = 0.0
-        if cfg.running_mean is not None:
-            mom = cfg.momentum
-            if mom is None:  # cumulative moving average (host sync, like the stock module)
-                mom = 1.0 / (float(cfg.num_batches_tracked.item()) + 1.0)
         mean, invstd = be.bn_finalize(stats, cnt, cfg.eps, cfg.running_mean, cfg.running_var, mom,
                                       cfg.num_batches_tracked if cfg.running_mean is not None else None)
     else:
         mean = cfg.running_mean.float()
         invstd = torch.rsqrt(cfg.running_var.float() + cfg.eps)
-    return mean, invstd, count, count_t, world
+    return mean, invstd, count, count_t, world, None
 
 
 class _PendingAffine:
@@ -288,7 +310,7 @@ class _BNActFn(torch.autograd.Function):
             if why is not None:
                 _note_fallback("bn_act", why)
                 be = reference
-        mean, invstd, count, count_t, world = _bn_moments(be, x, stats, cfg)
+        mean, invstd, count, count_t, world, ctx.ipc = _bn_moments(be, x, stats, cfg)
         c = x.shape[1]
         g32 = gamma.float() if gamma is not None else torch.ones(c, device=x.device)
         b32 = beta.float() if beta is not None else torch.zeros(c, device=x.device)
@@ -330,7 +352,11 @@ class _BNActFn(torch.autograd.Function):
         want_res = has_res and ctx.needs_input_grad[3]
         lazy = want_res and ctx.lazy_res and gate is None
         want_dres = want_res and not lazy
-        if cfg.training and world > 1:
+        if cfg.training and world > 1 and ctx.ipc is not None:
+            # the kernel exchanges the two sums with the peers itself; `sums` stays local (DDP averages the affine grads)
+            dx, dres, sums = be.bn_bwd_elemt(dz, z, x, mean, invstd, g32, psums, count_t, relu, want_dres,
+                                             ipc=ctx.ipc.native)
+        elif cfg.training and world > 1:
             # the affine grads stay local (DDP averages them); the sums that feed grad_input are global
             sums = be.bn_sum_partials(psums)
             gsums = sums.clone()
@@ -709,7 +735,7 @@ class _BNReluPoolFn(torch.autograd.Function):
             if why is not None:
                 _note_fallback("bn_relu_maxpool", why)
                 be = reference
-        mean, invstd, count, count_t, world = _bn_moments(be, u, stats, cfg)
+        mean, invstd, count, count_t, world, ctx.ipc = _bn_moments(be, u, stats, cfg)
         c = u.shape[1]
         g32 = gamma.float() if gamma is not None else torch.ones(c, device=u.device)
         b32 = beta.float() if beta is not None else torch.zeros(c, device=u.device)
@@ -725,7 +751,9 @@ class _BNReluPoolFn(torch.autograd.Function):
         # (the oracle's pool backward recomputes the pooling from its input: hand it the activation it kept)
         dz = be.maxpool3x3s2_bwd(_cl(dy), act if be is reference else u, y, aux)
         psums = be.bn_bwd_reduce(dz, act, u, mean, invstd, True)
-        if cfg.training and world > 1:
+        if cfg.training and world > 1 and ctx.ipc is not None:
+            du, _, sums = be.bn_bwd_elemt(dz, act, u, mean, invstd, g32, psums, count_t, True, False, ipc=ctx.ipc.native)
+        elif cfg.training and world > 1:
             sums = be.bn_sum_partials(psums)
             gsums = sums.clone()
             _small_all_reduce(gsums, cfg.group)

@@ -165,7 +165,19 @@ def bn_finalize(stats, count, eps: float, running_mean=None, running_var=None, m
     c, cd = _count_args(count)
     if stats.dim() == 2:
         stats = stats[None]
-    return _C.bn_finalize(stats.contiguous(), c, cd, eps, momentum, running_mean, running_var, num_batches_tracked)
+    return _C.bn_finalize(stats.contiguous(), c, cd, eps, momentum, running_mean, running_var, num_batches_tracked,
+                          None)[:2]
+
+
+def bn_finalize_sync(stats, count: float, eps: float, running_mean, running_var, momentum: float, num_batches_tracked,
+                     ipc):
+    """SyncBatchNorm: like ``bn_finalize``, but the kernel exchanges ``(count, mean, M2)`` with the other ranks
+    over the IPC mailboxes ``ipc`` (``_C.IpcAllReduce``) and merges them itself -> ``(mean, invstd, count_total)``
+    with ``count_total`` a 1-element device tensor."""
+    if stats.dim() == 2:
+        stats = stats[None]
+    return _C.bn_finalize(stats.contiguous(), float(count), None, eps, momentum, running_mean, running_var,
+                          num_batches_tracked, ipc)
 
 
 def bn_apply_act(x, mean, invstd, gamma, beta, residual=None, relu: bool = False, res_affine=None):
@@ -180,12 +192,14 @@ def bn_bwd_reduce(dz, z, x, mean, invstd, relu: bool):
     return _C.bn_bwd_reduce(dz, z if relu else None, x, mean, invstd, relu)
 
 
-def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, psums, count, relu: bool, want_dres: bool):
+def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, psums, count, relu: bool, want_dres: bool, ipc=None):
+    """``ipc`` (SyncBatchNorm): ``psums`` are this rank's partial rows, the kernel adds the other ranks' sums over the
+    IPC mailboxes itself; the returned ``sums`` stay local."""
     c, cd = _count_args(count)
     if psums.dim() == 2:
         psums = psums[None]
     dx, dres, sums = _C.bn_bwd_elemt(dz, z if relu else None, x, mean, invstd, gamma.contiguous(),
-                                     psums.contiguous(), c, cd, relu, want_dres)
+                                     psums.contiguous(), c, cd, relu, want_dres, ipc)
     return dx, (dres if want_dres else None), sums
 
 

@@ -92,6 +92,78 @@ def main() -> int:
     out["syncbn_rm_err"] = float((bn_sync.running_mean - bn_ref.running_mean).abs().max())
     out["syncbn_rv_err"] = float((bn_sync.running_var - bn_ref.running_var).abs().max())
 
+    # 4b. the exchange happens INSIDE the BN kernels: a SyncBN forward + backward launches exactly the kernels of a
+    # plain BN forward + backward (no packing, all-reduce, clone or fill launches around them); small tensor (the
+    # backward exchange runs in the prologue of the grad-input kernel) and a large one (in the coefficient kernel)
+    from torch.profiler import ProfilerActivity, profile
+
+    def kernels_of(fn):
+        torch.cuda.synchronize()
+        tdist.barrier()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fn()
+            torch.cuda.synchronize()
+        names = []
+        for e in prof.events():
+            if str(e.device_type).endswith("CUDA") and "memcpy" not in e.name.lower() and "memset" not in e.name.lower():
+                names.append(e.name.split("(")[0].split("<")[0].split("::")[-1])
+        return names
+
+    out["kernel_names"] = {}
+    for tag, shape in (("small", (per, c, 8, 8)), ("large", (64, c, 112, 112))):
+        xa = torch.randn(*shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        da = torch.randn(*shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+        def step(mod):
+            xi = xa.clone().requires_grad_(True)
+            mod(xi, relu=True).backward(da)
+
+        step(bn_ref), step(bn_sync)  # warm-up
+        k_ref = kernels_of(lambda: step(bn_ref))
+        k_sync = kernels_of(lambda: step(bn_sync))
+        out["kernel_names"][tag] = [k_ref, k_sync]
+
+    # 4d. cost of a SyncBN layer (forward + backward, CIFAR-sized ResNet-50 activations, 64 images per rank): plain BN,
+    # SyncBN with the exchange inside the BN kernels, SyncBN through the packed tensor + separate all-reduce kernel
+    import time
+
+    layers = [(64, 32), (256, 32), (128, 16), (512, 16), (256, 8), (1024, 8), (512, 4), (2048, 4)]
+    mods = []
+    for ch, hw in layers:
+        xa = torch.randn(64, ch, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        mods.append((pnn.BatchNorm2d(ch).to(dev), pnn.SyncBatchNorm(ch).to(dev), xa, torch.randn_like(xa)))
+
+    def sweep(which):
+        for ref_m, sync_m, xa, da in mods:
+            xi = xa.clone().requires_grad_(True)
+            (ref_m if which == "bn" else sync_m)(xi, relu=True).backward(da)
+
+    out["layer_us"] = {}
+    for which, ink in (("bn", "1"), ("syncbn_inkernel", "1"), ("syncbn_packed", "0")):
+        os.environ["PDT_SYNCBN_INKERNEL"] = ink
+        sweep(which)
+        torch.cuda.synchronize()
+        tdist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            sweep(which)
+        torch.cuda.synchronize()
+        out["layer_us"][which] = (time.perf_counter() - t0) / 20 / len(layers) * 1e6
+    os.environ["PDT_SYNCBN_INKERNEL"] = "1"
+
+    # 4c. statistics with |mean| = 100 std and a different mean on every rank: Chan's merge of (count, mean, M2)
+    # in the finalize kernel against a float64 computation over the concatenated batch
+    gen2 = torch.Generator().manual_seed(7)
+    big = torch.cat([(torch.randn(per, c, 8, 8, generator=gen2) + 100.0 + 3.0 * r) for r in range(world)])
+    big = big.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ref64 = big.double()
+    var64 = ref64.var(dim=(0, 2, 3), unbiased=False)
+    bn_big = pnn.SyncBatchNorm(c, momentum=1.0).to(dev)
+    bn_big(big[rank * per:(rank + 1) * per], relu=False)
+    out["syncbn_big_mean_err"] = float((bn_big.running_mean.double() - ref64.mean(dim=(0, 2, 3))).abs().max())
+    n_tot = big.numel() / c
+    out["syncbn_big_var_rel_err"] = float(((bn_big.running_var.double() * (n_tot - 1) / n_tot - var64) / var64).abs().max())
+
     # 5. a peer that never arrives: the kernel gives up after the limit, the flag is raised, the next call refuses
     torch.cuda.synchronize()
     tdist.barrier()

@@ -585,9 +585,16 @@ def test_ipc_small_allreduce_two_processes_on_one_gpu(tmp_path):
         assert o["syncbn_path"] == "ipc", o
         assert o["syncbn_fwd_err"] < 0.05 and o["syncbn_dx_err"] < 0.02, o
         assert o["syncbn_rm_err"] < 1e-4 and o["syncbn_rv_err"] < 1e-3, o
+        # the exchange runs inside the BN kernels: same launches as a plain BN, in both backward variants
+        for tag, (k_ref, k_sync) in o["kernel_names"].items():
+            assert sorted(k_ref) == sorted(k_sync) and len(k_ref) >= 4, (tag, k_ref, k_sync)
+        assert o["syncbn_big_mean_err"] < 1e-4 and o["syncbn_big_var_rel_err"] < 2e-3, o  # (fp32 partial rows inside a tile)
     r0 = [o for o in outs if o["rank"] == 0][0]
     assert r0["timed_out"] and r0["refused_after_timeout"], r0
     print("ipc all-reduce us/op:", r0["ipc_us"], " gloo-staged group us/op:", r0["group_us"])
+    print("us per BN layer (fwd+bwd), 2 ranks on one GPU:", r0["layer_us"])
+    # the in-kernel exchange must not cost more than the packed tensor + all-reduce kernel path it replaces
+    assert r0["layer_us"]["syncbn_inkernel"] < r0["layer_us"]["syncbn_packed"] * 1.05, r0["layer_us"]
 
 
 def test_bf16_gradient_buckets_follow_the_fp32_run():
