@@ -26,8 +26,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # them with what bench/micro/rccl_busbw.py measured on the node at hand (bus bandwidth, latency, bucket size).
 LINK_GBPS = 153.0          # xGMI per-link bandwidth
 COLL_LATENCY_US = 25.0     # launch + sync latency per RCCL collective (10-30 us)
-IPC_SMALL_US = 12.0        # one IpcAllReduce kernel (measured launch-to-launch with 2 processes on one MI355X;
-                           # across xGMI add the store round trip, a few us): the SyncBN statistics path
+IPC_SMALL_US = 5.0         # SyncBN statistics exchange inside the BN kernels: +9.7 us per layer for forward + backward
+                           # with 2 processes on one MI355X (profiles/r2_syncbn_inkernel.md); across xGMI add the
+                           # store round trip, a few us
 GRAD_BYTES = 25_557_032 * 4
 
 
