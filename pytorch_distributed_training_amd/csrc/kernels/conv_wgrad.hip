@@ -67,6 +67,11 @@ struct WgradArgs {
 // (An LDS-DMA ring variant of this kernel -- 3 or 4 stages, source-side swizzle, counted vmcnt as in conv_igemm.hip --
 // passed all numerics and measured 14.55 / 14.77 ms against 14.28 ms for this register-staged double buffer on
 // the sum of ResNet-50's weight gradients at B=1024, so it was not kept.)
+// (Round 2: 256 x 128 and 128 x 256 tiles -- 128 x 64 per wave, 1.5 transposed LDS reads per MFMA instead of 2, 2
+// workgroups per CU -- passed the tests and measured 8-12 % SLOWER on every ResNet-50 layer with >= 256 channels and
+// on ViT-B/16's linear layers at B = 1024 (bench/micro/wgrad_shapes.py: 256->256 3x3 347 -> 381 us, 512->2048 1x1
+// 154 -> 176 us, linear 768x2304 145 -> 173 us): with register-staged operands the kernel lives on its 12 waves
+// per CU hiding the global-load latency, not on LDS bandwidth.  Not kept.)
 template <int TNW, int TCW>
 __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                        float* __restrict__ slab, const WgradArgs a) {
@@ -265,7 +270,6 @@ void launch_cfg(const void* dy, const void* x, float* slab, const WgradGeom& g, 
 }
 
 inline int tile_w(int dim) { return dim % 128 == 0 ? 128 : 64; }
-
 }  // namespace
 
 // Workgroups the split-K factor aims for.  Pointwise layers want ~4 per CU (1024).  Spatial filters want shorter

@@ -94,7 +94,8 @@ def test_pointwise_conv_on_gemm_core_forced(kc, case):
 
 @pytest.mark.parametrize("case,splits", [
     ((3, 128, 21, 21, 128, 3, 1, 1), 7), ((5, 256, 9, 9, 1024, 1, 1, 0), 5), ((2, 64, 30, 30, 64, 3, 1, 1), 13),
-    ((3, 64, 23, 23, 128, 1, 1, 0), 9), ((3, 128, 20, 20, 64, 3, 2, 1), 4), ((2, 512, 7, 7, 512, 3, 1, 1), 3)])
+    ((3, 64, 23, 23, 128, 1, 1, 0), 9), ((3, 128, 20, 20, 64, 3, 2, 1), 4), ((2, 512, 7, 7, 512, 3, 1, 1), 3),
+    ((3, 256, 11, 11, 128, 1, 1, 0), 3), ((2, 256, 13, 13, 128, 3, 1, 1), 5), ((3, 128, 18, 18, 256, 3, 2, 1), 4)])
 def test_conv_wgrad_every_tile_with_split_k(kc, case, splits):
     """k_conv_wgrad<128,128>, <128,64>, <64,128>, <64,64> with several splits (ragged last split) + the slab reduce"""
     n = len(kc.RESULTS)
