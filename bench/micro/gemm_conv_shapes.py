@@ -31,3 +31,17 @@ for (cin, hw, cout) in [(64, 56, 256), (256, 56, 64), (128, 28, 512), (512, 28, 
     err = float((y.float() - _C.gemm_nt(a, w2)[0].float()).abs().max())
     byts = (M * cin + M * cout) * 2
     print(f"{cin:5d}->{cout:5d} @{hw:3d}  igemm+stats {us_ig:7.1f}  igemm {us_ig0:7.1f}  gemm {us_g:7.1f}  gemm+colsum {us_gc:7.1f} us   hbm bound {byts/5.5e6:7.1f} us  maxdiff {err:.3g}", flush=True)
+
+# 3x3 / stride 1 / pad 1: the core's spatial-filter mode (cfg 100) against the implicit-GEMM kernel (cfg 10 = its
+# 256x128 build, what the shape heuristic picks for these layers)
+for (c, hw) in [(256, 14), (512, 7), (128, 28), (64, 56)]:
+    x = torch.randn(B, c, hw, hw, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(c, c, 3, 3, device="cuda") * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn_like(x)
+    fl = 2.0 * B * hw * hw * c * c * 9
+    r = {}
+    for name, cfg in (("igemm", 0 if c < 256 else 10), ("core", 100)):
+        r[name + " fwd"] = t(lambda: native.conv2d_fwd(x, w, 1, 1, True, cfg=cfg))
+        r[name + " dgrad"] = t(lambda: native.conv2d_dgrad(dy, w, (B, c, hw, hw), 1, 1, cfg=cfg))
+    err = float((native.conv2d_fwd(x, w, 1, 1, False, cfg=100)[0].float() - native.conv2d_fwd(x, w, 1, 1, False, cfg=0 if c < 256 else 10)[0].float()).abs().max())
+    print(f"3x3 {c:4d}ch @{hw:3d}: " + "  ".join(f"{k} {v:7.1f} us ({fl / v / 1e6:5.0f} TF)" for k, v in r.items()) + f"  maxdiff {err:.3g}", flush=True)

@@ -131,6 +131,31 @@ bool conv_gemm_core_ok(long C, long N, long KH, long KW, long stride, long pad, 
     return cfg == 0 && enabled && eligible && N % 256 == 0;
 }
 
+// 3x3 / stride 1 / pad 1 on the GEMM core's spatial-filter mode (the taps go into the DMA's scalar offset, the zero
+// padding into per-row validity bits).  PDT_CONV_GEMM3=0 turns it off.
+bool conv_gemm_taps_ok(long B, long C, long N, long H, long W, long KH, long KW, long stride, long pad, int64_t cfg) {
+    static const bool enabled = [] {
+        const char* e = std::getenv("PDT_CONV_GEMM3");
+        return !(e && std::string(e) == "0");
+    }();
+    const bool eligible = KH == 3 && KW == 3 && stride == 1 && pad == 1 && C % 64 == 0 && N % 8 == 0 && W <= 126 &&
+                          B * H * W < (1L << 31);
+    if (cfg == kCfgGemmCore && eligible) return true;
+    return cfg == 0 && enabled && eligible && N % 256 == 0 && C >= 256;
+}
+// forward taps (dh, dw) = (r - pad, q - pad) with weight slot r * KW + q; data gradient: (pad - r, pad - q)
+void set_gemm_taps(GemmArgs& ga, long H, long W, long KH, long KW, long pad, bool dgrad) {
+    ga.ntaps = (int)(KH * KW);
+    ga.H = (int)H;
+    ga.W = (int)W;
+    for (int r = 0; r < KH; ++r)
+        for (int q = 0; q < KW; ++q) {
+            const int t = r * (int)KW + q;
+            const int dh = dgrad ? (int)pad - r : r - (int)pad, dw = dgrad ? (int)pad - q : q - (int)pad;
+            ga.tap[t] = (dh & 0xff) | ((dw & 0xff) << 8) | (t << 16);
+        }
+}
+
 std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, bool want_stats,
                                       int64_t cfg) {
     check_nhwc_bf16(x, "x");
@@ -144,12 +169,14 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
     TORCH_CHECK(Ho > 0 && Wo > 0, "empty output");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor y = empty_nhwc(B, N, Ho, Wo, x);
-    if (conv_gemm_core_ok(C, N, KH, KW, stride, pad, cfg)) {
+    const bool taps = conv_gemm_taps_ok(B, C, N, H, W, KH, KW, stride, pad, cfg);
+    if (taps || conv_gemm_core_ok(C, N, KH, KW, stride, pad, cfg)) {
         GemmArgs ga;
         std::memset(&ga, 0, sizeof(ga));
         ga.A = x.data_ptr(); ga.B = w.data_ptr(); ga.C = y.data_ptr();
         ga.M = B * H * W; ga.N = (int)N; ga.K = (int)C;
-        ga.lda = (int)C; ga.ldb = (int)C; ga.ldc = (int)N;
+        ga.lda = (int)C; ga.ldb = (int)(C * KH * KW); ga.ldc = (int)N;
+        if (taps) set_gemm_taps(ga, H, W, KH, KW, pad, false);
         Tensor slab, stats;
         const int m_tiles = gemm_m_tiles(ga.M);
         if (want_stats) {
@@ -253,14 +280,16 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
         g.is = 1; g.wtaps = KH * KW;
         return g;
     };
-    if (stride == 1 && !(addend_ptr && addend_stride == 2) && conv_gemm_core_ok(N, C, KH, KW, stride, pad, cfg)) {
-        // dx[M,Cin] = dy[M,Cout] . wt[Cin,Cout]^T on the GEMM core
+    const bool taps = conv_gemm_taps_ok(B, N, C, H, W, KH, KW, stride, pad, cfg);
+    if (stride == 1 && !(addend_ptr && addend_stride == 2) && (taps || conv_gemm_core_ok(N, C, KH, KW, stride, pad, cfg))) {
+        // dx[M,Cin] = dy[M,Cout] . wt[Cin,Cout]^T on the GEMM core (spatial filters: mirrored taps)
         Tensor dx = empty_nhwc(B, C, H, W, dy);
         GemmArgs ga;
         std::memset(&ga, 0, sizeof(ga));
         ga.A = dy.data_ptr(); ga.B = wt.data_ptr(); ga.C = dx.data_ptr();
         ga.M = B * H * W; ga.N = (int)C; ga.K = (int)N;
-        ga.lda = (int)N; ga.ldb = (int)N; ga.ldc = (int)C;
+        ga.lda = (int)N; ga.ldb = (int)(N * KH * KW); ga.ldc = (int)C;
+        if (taps) set_gemm_taps(ga, H, W, KH, KW, pad, true);
         Tensor psums, slab;
         const int m_tiles = gemm_m_tiles(ga.M);
         if (addend_ptr || bnr) {

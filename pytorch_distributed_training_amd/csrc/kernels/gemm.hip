@@ -82,7 +82,11 @@ __device__ __forceinline__ int stage_off(int s) { return s ? STAGE1_OFF : 0; }
 // (A variant in which waves 0-3 issued all operand DMA and waves 4-7 all output stores, so that no wave's counted
 // wait on its DMA also waits for its own older stores, measured within 2 % of this one on every pointwise shape of
 // ResNet-50 and on 4096^3: the store drain is not what short reductions wait for, and it was dropped.)
-template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV>
+// TAPS: the A rows are the pixels of an NHWC image and the reduction also runs over the taps of a spatial filter
+// (3x3, stride 1, same-size output): tap (dh, dw) reads the A row of pixel (y + dh, x + dw), which is the SAME row
+// pattern shifted by (dh * W + dw) rows -- a per-tap constant that goes into the DMA's scalar offset -- and only the
+// zero padding is per lane: 9 validity bits per staged row, computed once per tile.
+template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV, bool TAPS>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -109,6 +113,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
     // range check of the descriptor does not see: rows past the end of a ragged tile are masked explicitly.
     int lch[2];
     uint32_t vA[2], vB[2];
+    uint32_t tapmask[2][2];  // TAPS: bit t = tap t of staged A row (half h, piece j) reads inside the image
+    const int halo = TAPS ? a.W + 1 : 0;  // rows the A descriptor starts ahead of the tile (negative tap shifts)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = (wave * 2 + j) * 8 + (lane >> 3);
@@ -129,12 +135,34 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
         rows_m = (int)((a.M - m0) < BM ? (a.M - m0) : BM);
         rows_n = (a.N - n0) < BN ? (a.N - n0) : BN;
         // descriptors re-based at the tile's first row: offsets inside stay far below 2^31
-        ra = make_rsrc_words(static_cast<const char*>(a.A) + m0 * a.lda * 2, (uint32_t)((long)rows_m * a.lda * 2));
+        // (TAPS: the window is widened by the halo on both sides in case the range check sees the scalar offset;
+        // every lane whose shifted row leaves the image, and with it the tensor, is masked explicitly)
+        ra = make_rsrc_words(static_cast<const char*>(a.A) + (m0 - halo) * a.lda * 2,
+                             (uint32_t)((long)(rows_m + 2 * halo) * a.lda * 2));
         rb = make_rsrc_words(static_cast<const char*>(a.B) + (long)n0 * a.ldb * 2, (uint32_t)((long)rows_n * a.ldb * 2));
+        if (TAPS) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint32_t m = (uint32_t)(m0 + h * 128 + (wave * 2 + j) * 8 + (lane >> 3));  // < 2^31 pixels
+                    const uint32_t img = fdiv(m, a.div_hw);
+                    const uint32_t pix = m - img * a.div_hw.d;
+                    const int y = (int)fdiv(pix, a.div_w);
+                    const int x = (int)pix - y * (int)a.div_w.d;
+                    uint32_t bits = 0u;
+                    for (int t = 0; t < a.ntaps; ++t) {
+                        const int dh = (int)(int8_t)(a.tap[t] & 0xff), dw = (int)(int8_t)((a.tap[t] >> 8) & 0xff);
+                        const bool ok = (unsigned)(y + dh) < (unsigned)a.H && (unsigned)(x + dw) < (unsigned)a.W;
+                        bits |= ok ? (1u << t) : 0u;
+                    }
+                    tapmask[h][j] = bits;
+                }
+        }
     };
     const uint32_t piece_base = lds_address(smem) + (uint32_t)wave * 2048u;  // + j * 1024
 
-    const int nt = (a.K + BK - 1) / BK;
+    const int nt = TAPS ? a.ntaps * (a.K / BK) : (a.K + BK - 1) / BK;
     // slot: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi; t = K-tile of the current operand state; par = its stage buffer
     auto issue = [&](int hslot, int t, int par) {
         const uint32_t dst = piece_base + (uint32_t)(stage_off(par) + hslot * HALF_BYTES);
@@ -142,7 +170,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
         const int h = hslot & 1;
         const int ld2 = (isB ? a.ldb : a.lda) * 2;
         const int rows = isB ? rows_n : rows_m;
-        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(t * BK * 2 + h * 128 * ld2);
+        int koff = t * BK * 2, ti = 0;  // byte offset along the row, tap index
+        if (TAPS) {
+            ti = (int)fdiv((uint32_t)t, a.div_kt);
+            const int kc = t - ti * (int)a.div_kt.d;
+            const int32_t tp = a.tap[ti];
+            if (isB) koff = ((tp >> 16) * a.K + kc * BK) * 2;
+            else koff = kc * BK * 2 + ((int)(int8_t)(tp & 0xff) * a.W + (int)(int8_t)((tp >> 8) & 0xff) + halo) * ld2;
+        }
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(koff + h * 128 * ld2);
         const bool cut0 = RAGGED && t == nt - 1 && t * BK + lch[0] * 8 >= a.K;  // chunks past the end of the
         const bool cut1 = RAGGED && t == nt - 1 && t * BK + lch[1] * 8 >= a.K;  // reduction axis read zeros
 #pragma unroll
@@ -150,6 +186,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
             const int r = h * 128 + (wave * 2 + j) * 8 + (lane >> 3);
             uint32_t v = isB ? vB[j] : vA[j];
             if (r >= rows || (j ? cut1 : cut0)) v = kOOB;
+            if (TAPS && !isB && !((tapmask[h][j] >> ti) & 1u)) v = kOOB;
             lds_dma16s(isB ? rb : ra, v, soff, dst + (uint32_t)(j * 1024));
         }
     };
@@ -435,15 +472,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
 
 int gemm_m_tiles(long M) { return (int)((M + BM - 1) / BM); }
 
-template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV>
+template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV, bool TAPS = false>
 static void launch_variant(const GemmArgs& a, int grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV>),
+        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV, TAPS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV, TAPS>), dim3(grid), dim3(512), LDS_BYTES, s, a);
 }
 
 void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
@@ -467,6 +504,25 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
     const bool ragged = a.K % BK != 0, colsum = a.colsum_slab != nullptr;
     const int extra = a.residual ? 1 : (a.gelu_in ? 2 : 0);
     const bool act = a.act == 1;
+    if (a.ntaps > 0) {
+        // spatial filter: dense NHWC rows, K = channels per tap (a multiple of the K-tile), taps in the weight rows
+        const bool fused = a.addend || a.bnr_x;
+        if (ragged || extra || act || colsum || a.bias || a.ldc != a.N || a.lda != a.K || a.ntaps > 9 || a.H <= 0 ||
+            a.W <= 0 || a.W > 126 || a.M % ((long)a.H * a.W) != 0 || a.M >= (1L << 31) || (a.conv_mode == 1 && !a.stats_slab) ||
+            (a.conv_mode == 2 && (!fused || (a.bnr_x && !(a.stats_slab && a.bnr_mask && a.bnr_mean && a.bnr_invstd)) ||
+                                  (a.addend_mask && !a.addend))) ||
+            a.conv_mode > 2) {
+            fprintf(stderr, "launch_gemm_nt: unsupported spatial-filter launch\n");
+            abort();
+        }
+        a.div_w = make_fastdiv((uint32_t)a.W);
+        a.div_hw = make_fastdiv((uint32_t)(a.H * a.W));
+        a.div_kt = make_fastdiv((uint32_t)(a.K / BK));
+        if (a.conv_mode == 1) launch_variant<0, false, false, false, 1, true>(a, grid, s);
+        else if (a.conv_mode == 2) launch_variant<0, false, false, false, 2, true>(a, grid, s);
+        else launch_variant<0, false, false, false, 0, true>(a, grid, s);
+        return;
+    }
     if (a.conv_mode != 0) {
         // pointwise convolution in NHWC: dense rows (ld == channels), no bias
         const bool fused = a.addend || a.bnr_x;

@@ -231,6 +231,12 @@ struct GemmArgs {
     const uint8_t* bnr_mask;     // [M][N/8]: activity of the ReLU behind that BatchNorm
     const float* bnr_mean;       // [N]
     const float* bnr_invstd;     // [N]
+    // spatial filter as implicit GEMM (stride 1, output grid == input grid H x W, rows of A are pixels): K runs over
+    // ntaps x (K / 64) tiles; tap t reads pixel (y + tap_dh, x + tap_dw) of the same image (zeros outside) and the
+    // weight columns [tap_w * K, (tap_w + 1) * K) of B, whose rows are ldb = wtaps * K long.  ntaps == 0: plain GEMM.
+    int ntaps, H, W;
+    int32_t tap[9];  // (dh & 0xff) | (dw & 0xff) << 8 | wslot << 16
+    FastDiv div_w, div_hw, div_kt;  // / W, / (H * W), / (K / 64)
     int m_tiles, n_tiles, group_m;  // filled by the launcher
     int debug_nostore;              // timing diagnostics: the output descriptor gets zero records (stores dropped)
 };

@@ -85,7 +85,10 @@ def test_conv_every_igemm_build_forced(kc, cfg, case):
 @pytest.mark.parametrize("case", [
     (2, 64, 8, 8, 64, 1, 1, 0), (5, 64, 23, 23, 256, 1, 1, 0), (5, 256, 19, 19, 64, 1, 1, 0),
     (3, 128, 21, 21, 512, 1, 1, 0), (2, 512, 7, 7, 2048, 1, 1, 0), (2, 2048, 7, 7, 512, 1, 1, 0),
-    (9, 512, 14, 14, 640, 1, 1, 0), (16, 256, 56, 56, 64, 1, 1, 0), (16, 64, 56, 56, 256, 1, 1, 0)])
+    (9, 512, 14, 14, 640, 1, 1, 0), (16, 256, 56, 56, 64, 1, 1, 0), (16, 64, 56, 56, 256, 1, 1, 0),
+    # 3x3 / stride 1 / pad 1 in the core's spatial-filter mode (taps in the DMA's scalar offset, padding as per-row bits)
+    (3, 64, 9, 7, 128, 3, 1, 1), (2, 256, 14, 14, 256, 3, 1, 1), (3, 512, 7, 7, 512, 3, 1, 1), (2, 64, 30, 30, 64, 3, 1, 1),
+    (5, 128, 21, 21, 256, 3, 1, 1), (1, 256, 5, 3, 512, 3, 1, 1)])
 def test_pointwise_conv_on_gemm_core_forced(kc, case):
     n = len(kc.RESULTS)
     kc.check_conv(case, False, cfg=kc.GEMM_CORE)
