@@ -288,6 +288,7 @@ static long target_blocks(const WgradGeom& g) {
 }
 
 int conv_wgrad_splits(const WgradGeom& g) {
+    if (gemm_tn_ok(g)) return gemm_tn_splits(g);  // wide layers: 256 x 256 tiles, one workgroup per CU (gemm_tn.hip)
     const int tn = tile_w(g.N), tc = tile_w(g.C);
     const long tiles = (long)((g.N + tn - 1) / tn) * ((g.C + tc - 1) / tc) * g.KH * g.KW;
     const long M = (long)g.B * g.Hout * g.Wout;
@@ -307,6 +308,10 @@ int conv_wgrad_splits(const WgradGeom& g) {
 }
 
 void launch_conv_wgrad(const void* dy, const void* x, float* slab, const WgradGeom& g, hipStream_t s) {
+    if (gemm_tn_ok(g)) {
+        launch_gemm_tn(dy, x, slab, g, s);
+        return;
+    }
     const int tn = tile_w(g.N), tc = tile_w(g.C);
     if (tn == 128 && tc == 128) launch_cfg<128, 128>(dy, x, slab, g, s);
     else if (tn == 128) launch_cfg<128, 64>(dy, x, slab, g, s);

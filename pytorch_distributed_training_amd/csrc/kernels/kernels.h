@@ -240,6 +240,11 @@ struct GemmArgs {
     int m_tiles, n_tiles, group_m;  // filled by the launcher
     int debug_nostore;              // timing diagnostics: the output descriptor gets zero records (stores dropped)
 };
+// weight gradients of layers with Cout % 256 == 0 and Cin % 256 == 0 on 256 x 256 tiles (gemm_tn.hip); same slab
+// layout and split-K contract as launch_conv_wgrad, which dispatches to it
+bool gemm_tn_ok(const WgradGeom& g);
+int gemm_tn_splits(const WgradGeom& g);
+void launch_gemm_tn(const void* dy, const void* x, float* slab, const WgradGeom& g, hipStream_t s);
 int gemm_m_tiles(long M);
 void launch_gemm_nt(const GemmArgs& a, hipStream_t s);
 

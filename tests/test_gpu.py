@@ -98,7 +98,12 @@ def test_pointwise_conv_on_gemm_core_forced(kc, case):
 @pytest.mark.parametrize("case,splits", [
     ((3, 128, 21, 21, 128, 3, 1, 1), 7), ((5, 256, 9, 9, 1024, 1, 1, 0), 5), ((2, 64, 30, 30, 64, 3, 1, 1), 13),
     ((3, 64, 23, 23, 128, 1, 1, 0), 9), ((3, 128, 20, 20, 64, 3, 2, 1), 4), ((2, 512, 7, 7, 512, 3, 1, 1), 3),
-    ((3, 256, 11, 11, 128, 1, 1, 0), 3), ((2, 256, 13, 13, 128, 3, 1, 1), 5), ((3, 128, 18, 18, 256, 3, 2, 1), 4)])
+    ((3, 256, 11, 11, 128, 1, 1, 0), 3), ((2, 256, 13, 13, 128, 3, 1, 1), 5), ((3, 128, 18, 18, 256, 3, 2, 1), 4),
+    # Cout % 256 == 0 and Cin % 256 == 0: the 256x256 LDS-DMA kernel (gemm_tn.hip): default and forced split counts
+    # (ragged and empty last splits), 3x3 with padding, stride 2 (3x3 and 1x1), several tiles per operand
+    ((6, 256, 9, 9, 256, 3, 1, 1), 0), ((6, 256, 9, 9, 256, 3, 1, 1), 7), ((4, 256, 14, 14, 512, 3, 2, 1), 3),
+    ((4, 512, 12, 12, 256, 1, 2, 0), 2), ((3, 256, 11, 11, 768, 1, 1, 0), 11), ((5, 512, 7, 7, 512, 3, 1, 1), 0),
+    ((2, 256, 8, 8, 256, 1, 1, 0), 4), ((16, 1024, 14, 14, 256, 1, 1, 0), 0)])
 def test_conv_wgrad_every_tile_with_split_k(kc, case, splits):
     """k_conv_wgrad<128,128>, <128,64>, <64,128>, <64,64> with several splits (ragged last split) + the slab reduce"""
     n = len(kc.RESULTS)
