@@ -101,6 +101,7 @@ def conv_cases(quick):
 
 
 GEMM_CORE = 100  # cfg: the GEMM core (csrc/kernels/gemm.hip) instead of an implicit-GEMM build
+WIN64 = 101      # cfg: the 64-channel 3x3 window kernel (csrc/kernels/conv_win64.hip)
 
 
 def check_conv(args, time_it, cfg=0, splits=0):
@@ -187,7 +188,7 @@ def check_conv(args, time_it, cfg=0, splits=0):
                  rel_err(native.bn_sum_partials(ps5), native.bn_sum_partials(ps6)))
         ref_gate = (gate_src > 0)
         e2 = max(e2, rel_err(native.apply_relu_gate(add, gmask), add * ref_gate))
-        if cfg == GEMM_CORE:  # the same results from the implicit-GEMM kernel (bf16 roundings of identical sums)
+        if cfg in (GEMM_CORE, WIN64):  # the same results from the implicit-GEMM kernel (bf16 roundings of identical sums)
             dx0, ps0 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, add, (xb, act, mean, invstd), gmask, cfg=6)
             e2 = max(e2, rel_err(dx5, dx0), rel_err(native.bn_sum_partials(ps5), native.bn_sum_partials(ps0)))
             dxb, psb = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, p, None, (xb, act, mean, invstd), cfg=cfg)

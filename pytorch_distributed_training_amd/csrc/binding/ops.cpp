@@ -113,6 +113,8 @@ void check_conv_weight(const Tensor& w, const char* name) {
 
 // cfg selecting the GEMM core (gemm.hip) instead of an implicit-GEMM build; 0 = pick by shape
 constexpr int64_t kCfgGemmCore = 100;
+// cfg selecting the 64-channel 3x3 window kernel (conv_win64.hip); 0 picks it whenever the layer fits
+constexpr int64_t kCfgWin64 = 101;
 
 // A pointwise stride-1 convolution in NHWC is C[M,N] = A[M,K] . W[N,K]^T with dense rows.  Measured at B=1024 on
 // every pointwise shape of ResNet-50 (bench/micro/gemm_conv_shapes.py): with Cout a multiple of the 256-column
@@ -169,6 +171,15 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
     TORCH_CHECK(Ho > 0 && Wo > 0, "empty output");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor y = empty_nhwc(B, N, Ho, Wo, x);
+    if ((cfg == 0 || cfg == kCfgWin64) && conv_win64_ok((int)C, (int)N, (int)KH, (int)KW, (int)stride, (int)pad, (int)H, (int)W)) {
+        const int grid = conv_win64_grid((int)B, (int)H);
+        Tensor slab, stats;
+        if (want_stats) slab = at::empty({grid, 2, N}, x.options().dtype(at::kFloat));
+        launch_conv_win64(x.data_ptr(), w.data_ptr(), y.data_ptr(), want_stats ? slab.data_ptr<float>() : nullptr, (int)B,
+                          (int)H, (int)W, 0, nullptr, nullptr, nullptr, nullptr, cur_stream(x));
+        return {y, slab};
+    }
+    TORCH_CHECK(cfg != kCfgWin64, "the window kernel takes 3x3 / stride 1 / pad 1 convolutions with 64 -> 64 channels");
     const bool taps = conv_gemm_taps_ok(B, C, N, H, W, KH, KW, stride, pad, cfg);
     if (taps || conv_gemm_core_ok(C, N, KH, KW, stride, pad, cfg)) {
         GemmArgs ga;
@@ -280,6 +291,32 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
         g.is = 1; g.wtaps = KH * KW;
         return g;
     };
+    if ((cfg == 0 || cfg == kCfgWin64) && !addend_ptr &&
+        conv_win64_ok((int)N, (int)C, (int)KH, (int)KW, (int)stride, (int)pad, (int)H, (int)W)) {
+        Tensor dx = empty_nhwc(B, C, H, W, dy);
+        const int grid = conv_win64_grid((int)B, (int)H);
+        Tensor psums, slab;
+        const void* bx = nullptr;
+        const uint8_t* bm = nullptr;
+        const float *bmean = nullptr, *binv = nullptr;
+        if (bnr) {
+            check_nhwc_bf16(*bn_x, "bn_x");
+            TORCH_CHECK(bn_x->sizes().vec() == x_shape, "bn_x must have the shape of dx");
+            TORCH_CHECK(bn_mask.has_value() && bn_mask->is_cuda() && bn_mask->scalar_type() == at::kByte &&
+                            bn_mask->is_contiguous() && bn_mask->numel() == B * H * W * (C / 8),
+                        "bn_mask: expected contiguous uint8 [B*H*W, C/8]");
+            TORCH_CHECK(bn_mean.has_value() && bn_invstd.has_value(), "bn_mean / bn_invstd missing");
+            check_vec_f32(*bn_mean, C, "bn_mean"); check_vec_f32(*bn_invstd, C, "bn_invstd");
+            bx = bn_x->data_ptr(); bm = bn_mask->data_ptr<uint8_t>();
+            bmean = bn_mean->data_ptr<float>(); binv = bn_invstd->data_ptr<float>();
+            slab = at::empty({grid, 2 * C}, dy.options().dtype(at::kFloat));
+        }
+        launch_conv_win64(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), bnr ? slab.data_ptr<float>() : nullptr, (int)B, (int)H,
+                          (int)W, 1, bx, bm, bmean, binv, s);
+        if (bnr) psums = shrink_rows(slab, grid, 2 * C, kReduceChunks).view({-1, 2, C});
+        return {dx, psums};
+    }
+    if (cfg == kCfgWin64) cfg = 0;  // (with an addend: implicit-GEMM kernel)
     const bool taps = conv_gemm_taps_ok(B, N, C, H, W, KH, KW, stride, pad, cfg);
     if (stride == 1 && !(addend_ptr && addend_stride == 2) && (taps || conv_gemm_core_ok(N, C, KH, KW, stride, pad, cfg))) {
         // dx[M,Cin] = dy[M,Cout] . wt[Cin,Cout]^T on the GEMM core (spatial filters: mirrored taps)

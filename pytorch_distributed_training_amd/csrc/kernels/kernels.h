@@ -240,6 +240,12 @@ struct GemmArgs {
     int m_tiles, n_tiles, group_m;  // filled by the launcher
     int debug_nostore;              // timing diagnostics: the output descriptor gets zero records (stores dropped)
 };
+// 3x3 / stride 1 / pad 1 with 64 -> 64 channels: weights in registers, input window staged once per tile (conv_win64.hip)
+bool conv_win64_ok(int C, int N, int KH, int KW, int stride, int pad, int H, int W);
+int conv_win64_grid(int B, int H);
+void launch_conv_win64(const void* x, const void* w, void* y, float* slab, int B, int H, int W, int mirror,
+                       const void* bnr_x, const uint8_t* bnr_mask, const float* bnr_mean, const float* bnr_invstd,
+                       hipStream_t s);
 // weight gradients of layers with Cout % 256 == 0 and Cin % 256 == 0 on 256 x 256 tiles (gemm_tn.hip); same slab
 // layout and split-K contract as launch_conv_wgrad, which dispatches to it
 bool gemm_tn_ok(const WgradGeom& g);
