@@ -120,6 +120,14 @@ constexpr int64_t kCfgWin64 = 101;
 // every pointwise shape of ResNet-50 (bench/micro/gemm_conv_shapes.py): with Cout a multiple of the 256-column
 // tile the GEMM core is 0-35 % faster than the implicit-GEMM kernel (64->256 @56: 388 vs 572 us with the
 // statistics epilogue), with 64 / 128 output channels it loses (half-empty tiles).  PDT_CONV_GEMM=0 turns it off.
+// the 64-channel window kernel is persistent too (one workgroup per CU, tiles of 4 image rows): two tiles per CU at least
+bool win64_enough(long B, long H) { return B * ((H + 3) / 4) >= 512; }
+
+// The persistent 256x256 kernels want the chip full: below ~3/4 of the CUs' worth of tiles (the CIFAR-shaped step:
+// 32 tiles per layer) the small-tile implicit-GEMM kernel wins (measured on the 3x32x32 hipGraph step: 4.10 ms with
+// the round-1 kernels, 5.22 ms with the new ones on every layer, 4.1 again with this rule).
+bool enough_gemm_tiles(long M, long N) { return ((M + 255) / 256) * ((N + 255) / 256) >= 192; }
+
 bool conv_gemm_core_ok(long C, long N, long KH, long KW, long stride, long pad, int64_t cfg) {
     static const bool enabled = [] {
         const char* e = std::getenv("PDT_CONV_GEMM");
@@ -130,7 +138,7 @@ bool conv_gemm_core_ok(long C, long N, long KH, long KW, long stride, long pad, 
         TORCH_CHECK(eligible, "the GEMM core takes pointwise stride-1 convolutions with Cin % 64 == 0");
         return true;
     }
-    return cfg == 0 && enabled && eligible && N % 256 == 0;
+    return cfg == 0 && enabled && eligible && N % 256 == 0;  // (+ enough_gemm_tiles at the call sites, which know M)
 }
 
 // 3x3 / stride 1 / pad 1 on the GEMM core's spatial-filter mode (the taps go into the DMA's scalar offset, the zero
@@ -143,7 +151,7 @@ bool conv_gemm_taps_ok(long B, long C, long N, long H, long W, long KH, long KW,
     const bool eligible = KH == 3 && KW == 3 && stride == 1 && pad == 1 && C % 64 == 0 && N % 8 == 0 && W <= 126 &&
                           B * H * W < (1L << 31);
     if (cfg == kCfgGemmCore && eligible) return true;
-    return cfg == 0 && enabled && eligible && N % 256 == 0 && C >= 256;
+    return cfg == 0 && enabled && eligible && N % 256 == 0 && C >= 256 && enough_gemm_tiles(B * H * W, N);
 }
 // forward taps (dh, dw) = (r - pad, q - pad) with weight slot r * KW + q; data gradient: (pad - r, pad - q)
 void set_gemm_taps(GemmArgs& ga, long H, long W, long KH, long KW, long pad, bool dgrad) {
@@ -171,7 +179,8 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
     TORCH_CHECK(Ho > 0 && Wo > 0, "empty output");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     Tensor y = empty_nhwc(B, N, Ho, Wo, x);
-    if ((cfg == 0 || cfg == kCfgWin64) && conv_win64_ok((int)C, (int)N, (int)KH, (int)KW, (int)stride, (int)pad, (int)H, (int)W)) {
+    if ((cfg == kCfgWin64 || (cfg == 0 && win64_enough(B, H))) &&
+        conv_win64_ok((int)C, (int)N, (int)KH, (int)KW, (int)stride, (int)pad, (int)H, (int)W)) {
         const int grid = conv_win64_grid((int)B, (int)H);
         Tensor slab, stats;
         if (want_stats) slab = at::empty({grid, 2, N}, x.options().dtype(at::kFloat));
@@ -181,7 +190,7 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
     }
     TORCH_CHECK(cfg != kCfgWin64, "the window kernel takes 3x3 / stride 1 / pad 1 convolutions with 64 -> 64 channels");
     const bool taps = conv_gemm_taps_ok(B, C, N, H, W, KH, KW, stride, pad, cfg);
-    if (taps || conv_gemm_core_ok(C, N, KH, KW, stride, pad, cfg)) {
+    if (taps || (conv_gemm_core_ok(C, N, KH, KW, stride, pad, cfg) && (cfg == kCfgGemmCore || enough_gemm_tiles(B * H * W, N)))) {
         GemmArgs ga;
         std::memset(&ga, 0, sizeof(ga));
         ga.A = x.data_ptr(); ga.B = w.data_ptr(); ga.C = y.data_ptr();
@@ -291,7 +300,7 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
         g.is = 1; g.wtaps = KH * KW;
         return g;
     };
-    if ((cfg == 0 || cfg == kCfgWin64) && !addend_ptr &&
+    if ((cfg == kCfgWin64 || (cfg == 0 && win64_enough(B, H))) && !addend_ptr &&
         conv_win64_ok((int)N, (int)C, (int)KH, (int)KW, (int)stride, (int)pad, (int)H, (int)W)) {
         Tensor dx = empty_nhwc(B, C, H, W, dy);
         const int grid = conv_win64_grid((int)B, (int)H);
@@ -318,7 +327,8 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
     }
     if (cfg == kCfgWin64) cfg = 0;  // (with an addend: implicit-GEMM kernel)
     const bool taps = conv_gemm_taps_ok(B, N, C, H, W, KH, KW, stride, pad, cfg);
-    if (stride == 1 && !(addend_ptr && addend_stride == 2) && (taps || conv_gemm_core_ok(N, C, KH, KW, stride, pad, cfg))) {
+    if (stride == 1 && !(addend_ptr && addend_stride == 2) &&
+        (taps || (conv_gemm_core_ok(N, C, KH, KW, stride, pad, cfg) && (cfg == kCfgGemmCore || enough_gemm_tiles(B * H * W, C))))) {
         // dx[M,Cin] = dy[M,Cout] . wt[Cin,Cout]^T on the GEMM core (spatial filters: mirrored taps)
         Tensor dx = empty_nhwc(B, C, H, W, dy);
         GemmArgs ga;
@@ -1390,6 +1400,8 @@ void bind_ops(pybind11::module& m) {
     m.def("layernorm_fwd", &layernorm_fwd);
     m.def("layernorm_bwd", &layernorm_bwd, pybind11::arg("dy"), pybind11::arg("x"), pybind11::arg("mean"),
           pybind11::arg("rstd"), pybind11::arg("gamma"), pybind11::arg("addend") = pybind11::none());
+    m.def("set_wgrad_tn_min_rows", [](int64_t rows) { set_gemm_tn_min_rows((long)rows); },
+          "reduction length (output pixels / tokens) from which wide layers use the 256x256 weight-gradient kernel");
     m.def("set_activation_window", &set_activation_window,
           "bytes of one operand a convolution / pooling launch may span (tests shrink it to force batch chunking)");
     m.def("maxpool3x3s2_fwd", &maxpool3x3s2_fwd);

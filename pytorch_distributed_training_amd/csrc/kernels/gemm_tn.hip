@@ -269,9 +269,17 @@ bool tn_enabled() {
 
 }  // namespace
 
+static long g_tn_min_m = [] {
+    const char* e = std::getenv("PDT_WGRAD_TN_MIN_M");
+    return e ? std::atol(e) : 8192L;
+}();
+void set_gemm_tn_min_rows(long rows) { g_tn_min_m = rows; }
+
 bool gemm_tn_ok(const WgradGeom& g) {
     const long M = (long)g.B * g.Hout * g.Wout;
-    return tn_enabled() && g.N % 256 == 0 && g.C % 256 == 0 && M >= 4 * TKM && M < (1L << 31) &&
+    // (short reductions -- the CIFAR-shaped step has 512 to 8192 output pixels per layer -- stay on the small-tile
+    // kernel: one 256 x 256 fp32 slab tile per workgroup is then most of the traffic; PDT_WGRAD_TN_MIN_M overrides)
+    return tn_enabled() && g.N % 256 == 0 && g.C % 256 == 0 && M >= g_tn_min_m && M >= 4 * TKM && M < (1L << 31) &&
            (long)g.B * g.Hin * g.Win * g.C * 2 < (1L << 31);
 }
 

@@ -249,6 +249,7 @@ void launch_conv_win64(const void* x, const void* w, void* y, float* slab, int B
 // weight gradients of layers with Cout % 256 == 0 and Cin % 256 == 0 on 256 x 256 tiles (gemm_tn.hip); same slab
 // layout and split-K contract as launch_conv_wgrad, which dispatches to it
 bool gemm_tn_ok(const WgradGeom& g);
+void set_gemm_tn_min_rows(long rows);  // reduction length from which it is used (default 8192; tests lower it)
 int gemm_tn_splits(const WgradGeom& g);
 void launch_gemm_tn(const void* dy, const void* x, float* slab, const WgradGeom& g, hipStream_t s);
 int gemm_m_tiles(long M);

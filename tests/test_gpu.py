@@ -119,7 +119,12 @@ def test_conv3x3_64ch_window_kernel_forced(kc, case):
 def test_conv_wgrad_every_tile_with_split_k(kc, case, splits):
     """k_conv_wgrad<128,128>, <128,64>, <64,128>, <64,64> with several splits (ragged last split) + the slab reduce"""
     n = len(kc.RESULTS)
-    kc.check_conv(case, False, splits=splits)
+    ext = pdt.require_native()
+    ext.set_wgrad_tn_min_rows(128)  # (production: 8192 output pixels; these shapes are small on purpose)
+    try:
+        kc.check_conv(case, False, splits=splits)
+    finally:
+        ext.set_wgrad_tn_min_rows(8192)
     _assert_all_ok(kc, n)
 
 
@@ -191,6 +196,12 @@ def test_linear_wgrad_and_vit_glue_kernels():
     dw = native.linear_wgrad(dy, x)
     ref = dy.float().t() @ x.float()
     assert dw.dtype == torch.float32 and ((dw - ref).abs() / (ref.abs() + ref.abs().mean())).max() < 1e-3
+    # both widths multiples of 256 and >= 8192 tokens: the 256x256 LDS-DMA kernel (gemm_tn.hip), ragged last split
+    dy = torch.randn(9001, 768, device="cuda", generator=g).to(torch.bfloat16)[:9000]
+    x = torch.randn(9000, 1024, device="cuda", generator=g).to(torch.bfloat16)
+    dw = native.linear_wgrad(dy, x)
+    ref = dy.float().t() @ x.float()
+    assert ((dw - ref).abs() / (ref.abs() + ref.abs().mean())).max() < 1e-3
     img = torch.randn(3, 3, 64, 64, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     assert torch.equal(native.patchify(img, 16), reference.patchify(img, 16))
     tok = torch.randn(5, 16, 768, device="cuda", generator=g).to(torch.bfloat16)
