@@ -327,7 +327,17 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
     }
     if (cfg == kCfgWin64) cfg = 0;  // (with an addend: implicit-GEMM kernel)
     const bool taps = conv_gemm_taps_ok(B, N, C, H, W, KH, KW, stride, pad, cfg);
-    if (stride == 1 && !(addend_ptr && addend_stride == 2) &&
+    // With everything fused into its epilogue (gated addend + BN-backward sums: three activation-sized streams next to
+    // one K-tile of MFMAs) the layer-1 launch (Cout = 64) is a streaming kernel, and the 256x128 implicit-GEMM build
+    // with two workgroups per CU keeps more loads in flight than one persistent workgroup: 1435 vs 1600 us at B = 1280
+    // (bench/micro/fat_dgrad.py; from Cout = 128 on the two are within 2 %, at Cout = 512 the GEMM core wins by 6 %).
+    static const bool stream_rule = [] {
+        const char* e = std::getenv("PDT_FUSED_DGRAD_IGEMM");
+        return !(e && std::string(e) == "0");
+    }();
+    const bool fused_stream = stream_rule && (addend_ptr || bnr) && KH == 1 && KW == 1 && N <= 64 && cfg == 0;
+    if (fused_stream) cfg = 10;
+    if (stride == 1 && !(addend_ptr && addend_stride == 2) && !fused_stream &&
         (taps || (conv_gemm_core_ok(N, C, KH, KW, stride, pad, cfg) && (cfg == kCfgGemmCore || enough_gemm_tiles(B * H * W, C))))) {
         // dx[M,Cin] = dy[M,Cout] . wt[Cin,Cout]^T on the GEMM core (spatial filters: mirrored taps)
         Tensor dx = empty_nhwc(B, C, H, W, dy);
