@@ -859,6 +859,38 @@ std::tuple<Tensor, Tensor, Tensor> bn_bwd_elemt(const Tensor& dz, const c10::opt
     return {dx, dres, sums};
 }
 
+// bn_bwd_elemt of two BatchNorms that share the gradient dz and its ReLU mask (z = relu(bn_a(xa) + bn_b(xb))):
+// -> (dxa, dxb, sums_a, sums_b)
+std::tuple<Tensor, Tensor, Tensor, Tensor> bn_bwd_elemt2(
+    const Tensor& dz, const c10::optional<Tensor>& z, const Tensor& xa, const Tensor& mean_a, const Tensor& invstd_a,
+    const Tensor& gamma_a, const Tensor& psums_a, const Tensor& xb, const Tensor& mean_b, const Tensor& invstd_b,
+    const Tensor& gamma_b, const Tensor& psums_b, double count, const c10::optional<Tensor>& count_dev,
+    const std::shared_ptr<IpcAllReduce>& ipc) {
+    check_nhwc_bf16(dz, "dz"); check_nhwc_bf16(xa, "xa"); check_nhwc_bf16(xb, "xb");
+    TORCH_CHECK(dz.sizes() == xa.sizes() && dz.sizes() == xb.sizes(), "dz/xa/xb shape mismatch");
+    const long C = xa.size(1), M = xa.numel() / C;
+    TORCH_CHECK(bn_channels_ok(C), "bn: unsupported channel count ", C);
+    for (const Tensor* v : {&mean_a, &invstd_a, &gamma_a, &mean_b, &invstd_b, &gamma_b}) check_vec_f32(*v, C, "bn vector");
+    for (const Tensor* p : {&psums_a, &psums_b}) {
+        check_partials(*p, "psums");
+        TORCH_CHECK(p->size(2) == C, "psums: expected [P, 2, C]");
+    }
+    const void* zp = (z.has_value() && z->defined()) ? relu_mask_ptr(z, M, C) : nullptr;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(xa.device());
+    Tensor dxa = at::empty_like(xa), dxb = at::empty_like(xb);
+    Tensor sums = at::empty({2, 2, C}, psums_a.options());
+    Tensor coef = at::empty({2, 3, C}, psums_a.options());
+    BnBwdSide a{xa.data_ptr(), dxa.data_ptr(), mean_a.data_ptr<float>(), invstd_a.data_ptr<float>(),
+                gamma_a.data_ptr<float>(), psums_a.data_ptr<float>(), (int)psums_a.size(0), sums.data_ptr<float>(),
+                coef.data_ptr<float>()};
+    BnBwdSide b{xb.data_ptr(), dxb.data_ptr(), mean_b.data_ptr<float>(), invstd_b.data_ptr<float>(),
+                gamma_b.data_ptr<float>(), psums_b.data_ptr<float>(), (int)psums_b.size(0),
+                sums.data_ptr<float>() + 2 * C, coef.data_ptr<float>() + 3 * C};
+    launch_bn_bwd_elemt2(dz.data_ptr(), zp, M, (int)C, (float)count, count_ptr(count_dev), a, b, cur_stream(xa),
+                         ipc && ipc->world_size() > 1 ? &ipc->mailboxes_for(2 * C) : nullptr);
+    return {dxa, dxb, sums[0], sums[1]};
+}
+
 // -------------------------------------------------------------------------------- layernorm
 std::tuple<Tensor, Tensor, Tensor> layernorm_fwd(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps) {
     TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kBFloat16 && x.is_contiguous() && x.dim() >= 2,
@@ -1405,6 +1437,7 @@ void bind_ops(pybind11::module& m) {
           pybind11::arg("res_affine") = pybind11::none());
     m.def("bn_bwd_reduce", &bn_bwd_reduce);
     m.def("bn_bwd_elemt", &bn_bwd_elemt);
+    m.def("bn_bwd_elemt2", &bn_bwd_elemt2);
     m.def("attention_fwd", &attention_fwd);
     m.def("attention_bwd", &attention_bwd);
     m.def("layernorm_fwd", &layernorm_fwd);

@@ -511,6 +511,57 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
     if (exchange) ipc_end(mb, seq, late);
 }
 
+// Two BatchNorms that receive the SAME gradient (the last BN of a bottleneck and the BN of its downsample branch:
+// z = relu(bn3(x) + bn_ds(x_ds))) in one streaming pass: dz and the ReLU mask are read once instead of twice.
+// Both coefficient tables come from k_bn_bwd_coef.
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt2(const bf16* __restrict__ dz, const uint8_t* __restrict__ mask,
+                                                            const bf16* __restrict__ xa, const bf16* __restrict__ xb,
+                                                            bf16* __restrict__ dxa, bf16* __restrict__ dxb, long M,
+                                                            int C, const float* __restrict__ coef_a,
+                                                            const float* __restrict__ coef_b) {
+    const Map m = make_map(C);
+    float a1[8], a2[8], a3[8], b1[8], b2[8], b3[8];
+    ld8f(coef_a + m.cg * 8, a1);
+    ld8f(coef_a + C + m.cg * 8, a2);
+    ld8f(coef_a + 2 * C + m.cg * 8, a3);
+    ld8f(coef_b + m.cg * 8, b1);
+    ld8f(coef_b + C + m.cg * 8, b2);
+    ld8f(coef_b + 2 * C + m.cg * 8, b3);
+    constexpr int U = kUnroll / 2 > 0 ? kUnroll / 2 : 1;  // three input streams: half the rows in flight per trip
+    const long S = m.R;
+    const long T = (long)gridDim.x * U * m.R;
+    for (long rb = (long)blockIdx.x * U * m.R + m.rl; rb < M; rb += T) {
+        bf16x8 g[U], va[U], vb[U];
+        unsigned bits[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long r = rb + u * S;
+            bits[u] = 0xffu;
+            if (r < M) {
+                g[u] = ld8(dz + r * C + m.cg * 8);
+                va[u] = ld8(xa + r * C + m.cg * 8);
+                vb[u] = ld8(xb + r * C + m.cg * 8);
+                if (mask != nullptr) bits[u] = mask[r * m.G + m.cg];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long r = rb + u * S;
+            if (r >= M) break;
+            const long off = r * C + m.cg * 8;
+            float oa[8], ob[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gg = ((bits[u] >> k) & 1u) ? (float)g[u][k] : 0.f;
+                oa[k] = a1[k] * gg + a2[k] * (float)va[u][k] + a3[k];
+                ob[k] = b1[k] * gg + b2[k] * (float)vb[u][k] + b3[k];
+            }
+            st8(dxa + off, oa);
+            st8(dxb + off, ob);
+        }
+    }
+}
+
 // Grid of the streaming kernels: ONE chunk (kUnroll * R adjacent rows, 16 KiB per tensor) per block, blocks
 // dispatched in order -> the chip walks each tensor front to back like a plain vectorised elementwise
 // kernel does (5.8 TB/s; a 2048-block grid-stride loop over the same rows reached 5.1, hbm_ceiling.py).
@@ -723,6 +774,21 @@ void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx,
     else if (dres) PDT_ELEMT(false, true);
     else PDT_ELEMT(false, false);
 #undef PDT_ELEMT
+}
+
+void launch_bn_bwd_elemt2(const void* dz, const void* mask, long M, int C, float count, const float* count_dev,
+                          const BnBwdSide& a, const BnBwdSide& b, hipStream_t s, const IpcMailboxes* mbp) {
+    const IpcMailboxes mb = mbp ? *mbp : no_exchange();
+    const int R = kThreads / (C >> 3);
+    const BnBwdSide* sides[2] = {&a, &b};
+    for (const BnBwdSide* p : sides)  // SyncBatchNorm: one exchange per table, in the same order on every rank
+        hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 31) / 32), dim3(kThreads), 0, s, p->psums, p->nps, C, p->mean,
+                           p->invstd, p->gamma, count, count_dev, p->sums_out, p->coef, mb);
+    const int U = kUnroll / 2 > 0 ? kUnroll / 2 : 1;
+    const long blocks = (M + (long)R * U - 1) / ((long)R * U);
+    hipLaunchKernelGGL(k_bn_bwd_elemt2, dim3((unsigned)blocks), dim3(kThreads), 0, s, (const bf16*)dz,
+                       (const uint8_t*)mask, (const bf16*)a.x, (const bf16*)b.x, (bf16*)a.dx, (bf16*)b.dx, M, C,
+                       (const float*)a.coef, (const float*)b.coef);
 }
 
 namespace {

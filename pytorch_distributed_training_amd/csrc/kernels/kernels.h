@@ -101,6 +101,18 @@ void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx,
                          float* coef /*[3][C] workspace or null*/, hipStream_t s,
                          const IpcMailboxes* mb = nullptr /* SyncBatchNorm: global sums exchanged in the kernel */);
 
+// Two BatchNorms fed by ONE gradient (bottleneck bn3 + downsample BN): dz and the ReLU mask (may be null) are read
+// once; per side the partial sums of its own reduction, outputs dx, the summed [2][C] and a [3][C] workspace.
+struct BnBwdSide {
+    const void* x;
+    void* dx;
+    const float *mean, *invstd, *gamma, *psums;
+    int nps;
+    float *sums_out, *coef;
+};
+void launch_bn_bwd_elemt2(const void* dz, const void* mask, long M, int C, float count, const float* count_dev,
+                          const BnBwdSide& a, const BnBwdSide& b, hipStream_t s, const IpcMailboxes* mb = nullptr);
+
 // ---- LayerNorm over the last dim of [M, D] bf16 (layernorm.hip) -----------------------------------
 bool layernorm_dim_ok(int D);
 int layernorm_bwd_blocks(long M);  // rows of the dgamma / dbeta partial slab

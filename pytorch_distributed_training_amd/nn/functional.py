@@ -289,18 +289,23 @@ class _PendingAffine:
     ``(mean, invstd, gamma, beta)`` while it reads the tensor (``bn_apply_act(..., res_affine=...)``).  The backward
     of the deferring node is unchanged: the gradient w.r.t. its (virtual) output is what the consumer returns for
     its residual.  ``consumed`` is checked in that backward: an un-normalised tensor that went anywhere else is an
-    error, not a silently wrong activation."""
+    error, not a silently wrong activation.
 
-    __slots__ = ("operands", "consumed")
+    ``owner`` / ``result`` serve the backward: the consumer receives the gradient that is ALSO the deferring node's
+    gradient (gated by the consumer's ReLU mask), so it computes both input gradients in one pass over it
+    (``bn_bwd_elemt2``) and leaves the deferring node's share in ``result``."""
+
+    __slots__ = ("operands", "consumed", "owner", "result")
 
     def __init__(self):
         self.operands, self.consumed = None, False
+        self.owner = self.result = None
 
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, stats, cfg: BNConfig, relu: bool, sink=None, lazy_res: bool = False,
-                defer=None, res_affine=None):
+                defer=None, res_affine=None, res_pend=None):
         be = backend_for(x)
         x = _cl(x)
         if residual is not None:
@@ -317,11 +322,13 @@ class _BNActFn(torch.autograd.Function):
         ctx.defer = defer
         if defer is not None:  # (relu False, no residual: checked by bn_act) the consumer applies the affine
             defer.operands = (mean, invstd, g32, b32)
+            defer.owner = (x, mean, invstd, g32, count, world, ctx.ipc, be, cfg.training)
             z, act = x.view_as(x), None
         elif res_affine is not None:
             z, act = be.bn_apply_act(x, mean, invstd, g32, b32, residual, relu, res_affine)
         else:
             z, act = be.bn_apply_act(x, mean, invstd, g32, b32, residual, relu)
+        ctx.res_pend = res_pend if res_affine is not None else None
         ctx.sink = None
         if sink is not None and relu and be is not reference and act is not None and act.dtype == torch.uint8:
             sink.arm(x, act, mean, invstd)
@@ -342,6 +349,14 @@ class _BNActFn(torch.autograd.Function):
         psums = ctx.sink.take(dz) if ctx.sink is not None else None  # reduced by the consumer conv's dgrad epilogue
         gate = _take_gate(dz, getattr(ctx, "expect_gate", False))
         dz = _cl(dz)
+        if ctx.defer is not None:
+            done, ctx.defer.result, ctx.defer.owner = ctx.defer.result, None, None
+            if done is not None and done[2] == dz.data_ptr() and done[3] == dz._version:
+                # the consumer's backward already produced this node's input gradient (bn_bwd_elemt2)
+                dx, sums = done[0], done[1]
+                dgamma = sums[1].to(gdt) if (gdt is not None and ctx.needs_input_grad[1]) else None
+                dbeta = sums[0].to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
+                return (dx if ctx.needs_input_grad[0] else None), dgamma, dbeta, None, None, None, None, None, None, None, None, None
         if gate is not None:
             if relu:  # (not produced by the models here: a gated gradient into a BN that has its own ReLU)
                 dz = be.apply_relu_gate(dz, gate)
@@ -352,7 +367,24 @@ class _BNActFn(torch.autograd.Function):
         want_res = has_res and ctx.needs_input_grad[3]
         lazy = want_res and ctx.lazy_res and gate is None
         want_dres = want_res and not lazy
-        if cfg.training and world > 1 and ctx.ipc is not None:
+        pend, other = ctx.res_pend, None
+        if (DUAL_BN_BACKWARD and pend is not None and pend.owner is not None and lazy and relu and cfg.training
+                and ctx.needs_input_grad[0] and z is not None and (world == 1 or ctx.ipc is not None)):
+            ox, omean, oinvstd, og32, ocount, oworld, oipc, obe, otraining = pend.owner
+            if (obe is be and otraining and oworld == world and ocount == count and oipc is ctx.ipc
+                    and ox.shape == x.shape and ox.dtype == x.dtype):
+                other = (ox, omean, oinvstd, og32)
+        if other is not None:
+            # relu(bn(x) + bn_ds(x_ds)): the downsample BN receives this same dz with this same gate; one pass over
+            # dz and the mask produces both input gradients, its backward then only hands the result on
+            ox, omean, oinvstd, og32 = other
+            opsums = be.bn_bwd_reduce(dz, z, ox, omean, oinvstd, True)
+            dx, odx, sums, osums = be.bn_bwd_elemt2(dz, z, x, mean, invstd, g32, psums, ox, omean, oinvstd, og32,
+                                                     opsums, count_t if world > 1 else count,
+                                                     ipc=ctx.ipc.native if world > 1 else None)
+            pend.result = (odx, osums, dz.data_ptr(), dz._version)
+            dres = None
+        elif cfg.training and world > 1 and ctx.ipc is not None:
             # the kernel exchanges the two sums with the peers itself; `sums` stays local (DDP averages the affine grads)
             dx, dres, sums = be.bn_bwd_elemt(dz, z, x, mean, invstd, g32, psums, count_t, relu, want_dres,
                                              ipc=ctx.ipc.native)
@@ -375,9 +407,10 @@ class _BNActFn(torch.autograd.Function):
             dx = None
         if lazy:
             dres = _tag_gate(dz, z)  # ungated gradient + this node's ReLU mask: the producer of the residual gates it
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
+DUAL_BN_BACKWARD = os.environ.get("PDT_DUAL_BN_BACKWARD", "1") != "0"  # bn3 + downsample BN in one pass over dz
 _FUSE_BN_REDUCE = os.environ.get("PDT_FUSE_BN_REDUCE", "1") != "0"
 
 
@@ -404,11 +437,11 @@ def bn_act(x, gamma, beta, cfg: BNConfig, residual=None, relu: bool = False, sta
             lazy = True
     if relu and _FUSE_BN_REDUCE and x.is_cuda and torch.is_grad_enabled():
         sink = _BNSink()
-        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, True, sink, lazy, None, res_affine)
+        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, True, sink, lazy, None, res_affine, pend)
         if sink.x is not None:
             z._pdt_bn_sink = sink  # picked up by the conv node that consumes z
     else:
-        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, bool(relu), None, lazy, None, res_affine)
+        z = _BNActFn.apply(x, gamma, beta, residual, stats, cfg, bool(relu), None, lazy, None, res_affine, pend)
     if lazy and z.grad_fn is not None and getattr(z.grad_fn, "lazy_res", False):
         residual.grad_fn.expect_gate = True  # a gradient without its gate is now an error, not a wrong result
     if not relu and z.requires_grad:

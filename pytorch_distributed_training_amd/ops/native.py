@@ -203,6 +203,16 @@ def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, psums, count, relu: bool, want_d
     return dx, (dres if want_dres else None), sums
 
 
+def bn_bwd_elemt2(dz, z, xa, mean_a, invstd_a, gamma_a, psums_a, xb, mean_b, invstd_b, gamma_b, psums_b, count, ipc=None):
+    """Input gradients of two BatchNorms fed by the same gradient ``dz`` and ReLU mask ``z`` (bottleneck bn3 + the BN
+    of the downsample branch) in one pass over ``dz`` -> ``(dxa, dxb, sums_a, sums_b)``."""
+    c, cd = _count_args(count)
+    pa = psums_a[None] if psums_a.dim() == 2 else psums_a
+    pb = psums_b[None] if psums_b.dim() == 2 else psums_b
+    return _C.bn_bwd_elemt2(dz, z, xa, mean_a, invstd_a, gamma_a.contiguous(), pa.contiguous(), xb, mean_b, invstd_b,
+                            gamma_b.contiguous(), pb.contiguous(), c, cd, ipc)
+
+
 # ---------------------------------------------------------------- attention
 def attention_unsupported_reason(qkv, heads: int):
     if qkv.dtype != _BF16:

@@ -135,6 +135,14 @@ def bn_bwd_elemt(dz, z, x, mean, invstd, gamma, psums, count, relu: bool, want_d
     return dx.to(x.dtype), dres, sums
 
 
+def bn_bwd_elemt2(dz, z, xa, mean_a, invstd_a, gamma_a, psums_a, xb, mean_b, invstd_b, gamma_b, psums_b, count, ipc=None):
+    """Two BatchNorms fed by one gradient (``native.bn_bwd_elemt2``) -> ``(dxa, dxb, sums_a, sums_b)``."""
+    relu = z is not None
+    dxa, _, sa = bn_bwd_elemt(dz, z, xa, mean_a, invstd_a, gamma_a, psums_a, count, relu, False)
+    dxb, _, sb = bn_bwd_elemt(dz, z, xb, mean_b, invstd_b, gamma_b, psums_b, count, relu, False)
+    return dxa, dxb, sa, sb
+
+
 # ------------------------------------------------------------ attention ----
 def _split_heads(qkv, heads):
     b, s, w = qkv.shape

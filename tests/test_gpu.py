@@ -453,6 +453,35 @@ def test_batchnorm_statistics_with_mean_100_std(shape):
     assert ((invstd2.double() - inv_ref).abs() / inv_ref).max() < 2e-2
 
 
+@pytest.mark.parametrize("shape", [(4, 256, 56, 56), (3, 512, 7, 9), (2, 64, 5, 5), (64, 1024, 14, 14)])
+def test_bn_backward_of_two_norms_sharing_a_gradient(shape):
+    """bn_bwd_elemt2 (bottleneck bn3 + downsample BN, one pass over dz and the ReLU mask) against two bn_bwd_elemt
+    launches and against the fp32 formula."""
+    from pytorch_distributed_training_amd.ops import native, reference
+
+    torch.manual_seed(3)
+    B, C, H, W = shape
+    mk = lambda: torch.randn(B, C, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dz, xa, xb = mk(), mk() * 2 + 1, mk() * 0.5 - 2
+    count = float(B * H * W)
+    sides = []
+    for x in (xa, xb):
+        mean, invstd = native.bn_finalize(native.bn_stats(x), count, 1e-5)
+        sides.append((x, mean, invstd, torch.rand(C, device="cuda") + 0.5))
+    z, mask = native.bn_apply_act(xa, sides[0][1], sides[0][2], sides[0][3], torch.zeros(C, device="cuda"), xb, True)
+    assert mask.dtype == torch.uint8
+    ps = [native.bn_bwd_reduce(dz, mask, x, m, i, True) for x, m, i, _ in sides]
+    one = [native.bn_bwd_elemt(dz, mask, x, m, i, g, p, count, True, False) for (x, m, i, g), p in zip(sides, ps)]
+    (xa_, ma, ia, ga), (xb_, mb_, ib, gb) = sides
+    dxa, dxb, sa, sb = native.bn_bwd_elemt2(dz, mask, xa_, ma, ia, ga, ps[0], xb_, mb_, ib, gb, ps[1], count)
+    for got, (want, _, sums), s2 in ((dxa, one[0], sa), (dxb, one[1], sb)):
+        assert torch.allclose(s2, sums, rtol=1e-5, atol=1e-4)  # (the partial rows are summed in another order)
+        assert (got.float() - want.float()).abs().max() <= 2e-2 * want.float().abs().max()
+    for got, (x, m, i, g), p in ((dxa, sides[0], ps[0]), (dxb, sides[1], ps[1])):  # fp32 formula, gate = (z > 0)
+        want, _, _ = reference.bn_bwd_elemt(dz.float(), z.float(), x.float(), m, i, g, p, count, True, False)
+        assert (got.float() - want).abs().max() <= 2e-2 * want.abs().max()
+
+
 def test_dataflow_fusions_do_not_change_the_native_result(monkeypatch):
     """Gated residual gradient, deferred downsample BN, compact downsample gradient, fused stem tail and the
     BN-reduce-in-dgrad epilogue only re-arrange WHERE things are computed.  Switching each off on the native path:
@@ -473,7 +502,8 @@ def test_dataflow_fusions_do_not_change_the_native_result(monkeypatch):
     x = torch.randn(32, 3, 64, 64, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, 10, (32,), device="cuda")
     crit = pnn.CrossEntropyLoss()
-    knobs = [(R, "_LAZY_RES"), (R, "_DEFER_DS"), (R, "_COMPACT_DS"), (F, "_FUSE_STEM_POOL"), (F, "_FUSE_BN_REDUCE")]
+    knobs = [(R, "_LAZY_RES"), (R, "_DEFER_DS"), (R, "_COMPACT_DS"), (F, "_FUSE_STEM_POOL"), (F, "_FUSE_BN_REDUCE"),
+             (F, "DUAL_BN_BACKWARD")]
 
     def run(off=()):
         for mod, n in knobs:

@@ -425,6 +425,33 @@ def test_deferred_downsample_bn_matches_materialised(train, monkeypatch):
         assert torch.allclose(a.float(), b.float(), rtol=1e-6, atol=1e-7)
 
 
+def test_downsample_bn_backward_shares_the_pass_of_the_block_output_bn(monkeypatch):
+    """relu(bn3(x) + bn_ds(x_ds)): both BNs receive the same gated gradient, so the block-output node computes both
+    input gradients at once (bn_bwd_elemt2) and the downsample BN's backward only hands its share on."""
+    import pytorch_distributed_training_amd.nn.functional as F
+    import pytorch_distributed_training_amd.ops.reference as ref
+    from pytorch_distributed_training_amd.models import build_model
+
+    def run(dual):
+        monkeypatch.setattr(F, "DUAL_BN_BACKWARD", dual)
+        calls = []
+        orig = ref.bn_bwd_elemt2
+        monkeypatch.setattr(ref, "bn_bwd_elemt2", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        torch.manual_seed(0)
+        m = build_model("resnet50", 10)
+        x = torch.randn(2, 3, 32, 32, requires_grad=True)
+        m(x).square().sum().backward()
+        monkeypatch.setattr(ref, "bn_bwd_elemt2", orig)
+        return len(calls), x.grad.clone(), [p.grad.clone() for p in m.parameters()]
+
+    n1, gx1, gp1 = run(True)
+    n0, gx0, gp0 = run(False)
+    assert n1 == 4 and n0 == 0  # one downsample branch per stage
+    assert torch.allclose(gx1, gx0, rtol=1e-5, atol=1e-7)
+    for a, b in zip(gp1, gp0):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
 def test_deferred_bn_refuses_unaware_consumer():
     import pytorch_distributed_training_amd.nn as pnn
     from pytorch_distributed_training_amd.nn.functional import conv_bn_act
