@@ -573,9 +573,11 @@ std::tuple<Tensor, Tensor, Tensor> conv_stem_fwd(const Tensor& x, const Tensor& 
     const long per = chunk_images(B, std::max(xp_img, y_img));
     std::vector<int> tiles;
     int m_tiles = 0;
+    // (decided on the whole batch: every chunk takes the same kernel)
+    const bool win = conv_stem_win_ok((int)std::min(per, B), (int)Ho, (int)Wo, (int)N);
     for (long b0 = 0; b0 < B; b0 += per) {
         g.B = (int)std::min(per, B - b0);
-        tiles.push_back(conv_igemm_m_tiles(g, nullptr));
+        tiles.push_back(win ? conv_stem_win_grid(g.B, (int)Ho) : conv_igemm_m_tiles(g, nullptr));
         m_tiles += tiles.back();
     }
     Tensor stats, slab;
@@ -588,8 +590,12 @@ std::tuple<Tensor, Tensor, Tensor> conv_stem_fwd(const Tensor& x, const Tensor& 
     for (long b0 = 0; b0 < B; b0 += per, ++ci) {
         g.B = (int)std::min(per, B - b0);
         launch_stem_pack_x(at_image(x.data_ptr(), b0, x_img), at_image(xp.data_ptr(), b0, xp_img), g.B, (int)H, (int)W, s);
-        launch_conv_igemm(at_image(xp.data_ptr(), b0, xp_img), wp.data_ptr(), at_image(y.data_ptr(), b0, y_img), g,
-                          slab_ptr ? slab_ptr + row * 2 * N : nullptr, s);
+        if (win)
+            launch_conv_stem_win(at_image(xp.data_ptr(), b0, xp_img), wp.data_ptr(), at_image(y.data_ptr(), b0, y_img),
+                                 slab_ptr ? slab_ptr + row * 2 * N : nullptr, g.B, (int)Ho, (int)Wo, s);
+        else
+            launch_conv_igemm(at_image(xp.data_ptr(), b0, xp_img), wp.data_ptr(), at_image(y.data_ptr(), b0, y_img), g,
+                              slab_ptr ? slab_ptr + row * 2 * N : nullptr, s);
         row += tiles[ci];
     }
     if (want_stats) stats = shrink_rows(slab, m_tiles, 2 * N, kMaxFinalizeRows).view({-1, 2, N});
@@ -1424,6 +1430,7 @@ void bind_ops(pybind11::module& m) {
     m.def("conv2d_wgrad", &conv2d_wgrad, pybind11::arg("dy"), pybind11::arg("x"), pybind11::arg("kh"), pybind11::arg("kw"),
           pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("splits") = 0);
     m.def("conv_stem_fwd", &conv_stem_fwd);
+    m.def("set_stem_win_mode", &set_stem_win_mode);
     m.def("stem_pack_x", &stem_pack_x);
     m.def("conv_stem_wgrad", &conv_stem_wgrad);
     m.def("transpose_weight", &transpose_weight);

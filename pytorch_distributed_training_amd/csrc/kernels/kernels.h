@@ -281,5 +281,11 @@ void launch_vit_embed_bwd(const void* dx, void* dpatch, float* slab, int B, int 
 void launch_stem_pack_x(const void* x, void* xp, int B, int H, int W, hipStream_t s);
 // w [64][7][7][3] -> wp [64][7][8][4] (kw slot 0 and channel 3 are zero)
 void launch_stem_pack_w(const void* w, void* wp, int N, hipStream_t s);
+// forward on the packed image as a window kernel (conv_stem_win.hip): weights in registers, 8 output rows per tile;
+// slab [conv_stem_win_grid(B, Ho)][2][64] fp32 (per-channel sum / sum of squares of the rounded outputs) or null
+bool conv_stem_win_ok(int B, int Ho, int Wo, int N);
+int conv_stem_win_grid(int B, int Ho);
+void launch_conv_stem_win(const void* xp, const void* wp, void* y, float* slab, int B, int Ho, int Wo, hipStream_t s);
+void set_stem_win_mode(int mode);  // -1: PDT_STEM_WIN / work-size rule, 0 off, 2 whenever the geometry fits
 
 }  // namespace pdt

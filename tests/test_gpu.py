@@ -260,6 +260,34 @@ def test_vit_native_matches_fp32_oracle_gradients():
         assert 0.9 < (g.norm() / gr.norm().clamp_min(1e-12)).item() < 1.1, n
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32), (3, 96, 64), (2, 40, 32), (5, 224, 224), (300, 32, 32)])
+def test_stem_conv_window_kernel_forced(kc, shape):
+    """conv_stem_win.hip (weights in registers, 8 output rows per tile, persistent grid) on shapes the work-size rule
+    would leave to the implicit-GEMM kernel, with partial last tiles (Ho % 8 != 0) and more tiles than CUs: against
+    the fp32 reference (kernel_check) and against the implicit-GEMM launch of the same packed operands."""
+    from pytorch_distributed_training_amd import _C
+    from pytorch_distributed_training_amd.ops import native
+
+    B, H, W = shape
+    torch.manual_seed(1)
+    x = torch.randn(B, 3, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, device="cuda") / 12).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    try:
+        _C.set_stem_win_mode(0)
+        y0, st0, _ = native.conv2d_fwd(x, w, 2, 3, True, True)
+        _C.set_stem_win_mode(2)
+        y1, st1, _ = native.conv2d_fwd(x, w, 2, 3, True, True)
+        assert st1.shape[0] == min(B * ((H // 2 + 7) // 8), torch.cuda.get_device_properties(0).multi_processor_count)
+        assert (y1.float() - y0.float()).abs().max() <= 1e-2 * y0.float().abs().max()
+        s0, s1 = native.bn_sum_partials(st0), native.bn_sum_partials(st1)
+        assert torch.allclose(s1, s0, rtol=2e-3, atol=2e-2 * float(s0.abs().max()) * 1e-1)
+        n = len(kc.RESULTS)
+        kc.check_stem(B, H, W, False)
+        _assert_all_ok(kc, n)
+    finally:
+        _C.set_stem_win_mode(-1)
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 32), (3, 64, 48), (4, 224, 224)])
 def test_stem_conv_native_fwd_wgrad(kc, shape):
     n = len(kc.RESULTS)
