@@ -628,6 +628,20 @@ Tensor conv_stem_wgrad(const Tensor& dy, const Tensor& xp) {
     const long wsize = N * 147;
     const long dy_img = Ho * Wo * N * 2, xp_img = Hp * Wp * 8;
     const long per = chunk_images(B, std::max(dy_img, xp_img));
+    if (conv_stem_wgrad_win_ok((int)std::min(per, B), (int)Ho, (int)Wo, (int)N)) {  // conv_stem_win.hip
+        long rows = 0;
+        for (long b0 = 0; b0 < B; b0 += per) rows += conv_stem_wgrad_win_grid((int)std::min(per, B - b0), (int)Ho);
+        Tensor slab = at::empty({rows, wsize}, dy.options().dtype(at::kFloat));
+        long row = 0;
+        for (long b0 = 0; b0 < B; b0 += per) {
+            const int nb = (int)std::min(per, B - b0);
+            launch_conv_stem_wgrad_win(at_image(dy.data_ptr(), b0, dy_img), at_image(xp.data_ptr(), b0, xp_img),
+                                       slab.data_ptr<float>() + row * wsize, nb, (int)Ho, (int)Wo, cur_stream(dy));
+            row += conv_stem_wgrad_win_grid(nb, (int)Ho);
+        }
+        Tensor flat = rows == 1 ? slab.view({wsize}) : reduce_slab(slab, (int)rows, wsize);
+        return flat.view({N, 7, 7, 3}).permute({0, 3, 1, 2});
+    }
     std::vector<WinGeom> plans;
     long rows = 0;
     for (long b0 = 0; b0 < B; b0 += per) {

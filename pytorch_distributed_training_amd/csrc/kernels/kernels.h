@@ -286,6 +286,10 @@ void launch_stem_pack_w(const void* w, void* wp, int N, hipStream_t s);
 bool conv_stem_win_ok(int B, int Ho, int Wo, int N);
 int conv_stem_win_grid(int B, int Ho);
 void launch_conv_stem_win(const void* xp, const void* wp, void* y, float* slab, int B, int Ho, int Wo, hipStream_t s);
+// weight gradient on the packed image (same file): slab [conv_stem_wgrad_win_grid(B, Ho)][64][147] fp32 partials
+bool conv_stem_wgrad_win_ok(int B, int Ho, int Wo, int N);
+int conv_stem_wgrad_win_grid(int B, int Ho);
+void launch_conv_stem_wgrad_win(const void* dy, const void* xp, float* slab, int B, int Ho, int Wo, hipStream_t s);
 void set_stem_win_mode(int mode);  // -1: PDT_STEM_WIN / work-size rule, 0 off, 2 whenever the geometry fits
 
 }  // namespace pdt

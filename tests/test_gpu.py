@@ -281,6 +281,13 @@ def test_stem_conv_window_kernel_forced(kc, shape):
         assert (y1.float() - y0.float()).abs().max() <= 1e-2 * y0.float().abs().max()
         s0, s1 = native.bn_sum_partials(st0), native.bn_sum_partials(st1)
         assert torch.allclose(s1, s0, rtol=2e-3, atol=2e-2 * float(s0.abs().max()) * 1e-1)
+        dy = torch.randn(B, 64, H // 2, W // 2, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        xp = native.conv2d_fwd(x, w, 2, 3, False, True)[2]
+        dw1 = native.conv2d_wgrad(dy, xp, (64, 3, 7, 7), 2, 3)
+        _C.set_stem_win_mode(0)
+        dw0 = native.conv2d_wgrad(dy, xp, (64, 3, 7, 7), 2, 3)
+        _C.set_stem_win_mode(2)
+        assert (dw1 - dw0).abs().max() <= 2e-3 * dw0.abs().max()
         n = len(kc.RESULTS)
         kc.check_stem(B, H, W, False)
         _assert_all_ok(kc, n)
