@@ -501,6 +501,20 @@ Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, i
         Tensor flat = rows == 1 ? slab.view({wsize}) : reduce_slab(slab, (int)rows, wsize);
         return flat.view({N, KH, KW, C}).permute({0, 3, 1, 2});  // physical [N][KH][KW][C] == channels_last [N,C,KH,KW]
     };
+    if (splits <= 0 && wgrad_win64_ok((int)std::min(per, B), (int)H, (int)W, (int)C, (int)N, (int)KH, (int)KW,
+                                      (int)stride, (int)pad)) {  // wgrad_win64.hip
+        long rows = 0;
+        for (long b0 = 0; b0 < B; b0 += per) rows += wgrad_win64_grid((int)std::min(per, B - b0), (int)H);
+        Tensor slab = at::empty({rows, wsize}, x.options().dtype(at::kFloat));
+        long row = 0;
+        for (long b0 = 0; b0 < B; b0 += per) {
+            const int nb = (int)std::min(per, B - b0);
+            launch_wgrad_win64(at_image(dy.data_ptr(), b0, dy_img), at_image(x.data_ptr(), b0, x_img),
+                               slab.data_ptr<float>() + row * wsize, nb, (int)H, (int)W, cur_stream(x));
+            row += wgrad_win64_grid(nb, (int)H);
+        }
+        return finish(slab, rows);
+    }
     if (KH == 3 && KW == 3 && wgrad_win_enabled()) {  // all nine taps per workgroup from one staged window
         std::vector<WinGeom> plans;
         long rows = 0;
@@ -1445,6 +1459,7 @@ void bind_ops(pybind11::module& m) {
           pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("splits") = 0);
     m.def("conv_stem_fwd", &conv_stem_fwd);
     m.def("set_stem_win_mode", &set_stem_win_mode);
+    m.def("set_wgrad_win64_mode", &set_wgrad_win64_mode);
     m.def("stem_pack_x", &stem_pack_x);
     m.def("conv_stem_wgrad", &conv_stem_wgrad);
     m.def("transpose_weight", &transpose_weight);

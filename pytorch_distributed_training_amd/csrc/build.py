@@ -25,7 +25,7 @@ ARCH = "gfx950"
 HIP_SOURCES = [
     "kernels/elementwise.hip", "kernels/softmax_ce.hip", "kernels/bn.hip", "kernels/layernorm.hip", "kernels/attention.hip", "kernels/pool.hip",
     "kernels/gemm.hip", "kernels/gemm_tn.hip", "kernels/conv_win64.hip",
-    "kernels/conv_stem_win.hip", "kernels/vit.hip", "kernels/conv_igemm.hip", "kernels/conv_wgrad.hip", "kernels/conv_wgrad_win.hip", "kernels/conv_stem.hip",
+    "kernels/conv_stem_win.hip", "kernels/wgrad_win64.hip", "kernels/vit.hip", "kernels/conv_igemm.hip", "kernels/conv_wgrad.hip", "kernels/conv_wgrad_win.hip", "kernels/conv_stem.hip",
     "comm/ipc_allreduce.hip",
 ]
 # Kernels whose job is numerics (statistics, loss, optimizer, pooling, normalisation) keep NaN / Inf semantics:

@@ -202,6 +202,13 @@ int conv_wgrad_splits(const WgradGeom& g);
 void launch_conv_wgrad(const void* dy, const void* x, float* slab, const WgradGeom& g, hipStream_t s);
 
 
+// 64 -> 64 channel 3x3 / 1 / 1 weight gradient as a TN product out of an LDS window (wgrad_win64.hip);
+// slab [wgrad_win64_grid(B, H)][64][3][3][64] fp32, one partial per workgroup
+bool wgrad_win64_ok(int B, int H, int W, int C, int N, int KH, int KW, int stride, int pad);
+int wgrad_win64_grid(int B, int H);
+void launch_wgrad_win64(const void* dy, const void* x, float* slab, int B, int H, int W, hipStream_t s);
+void set_wgrad_win64_mode(int mode);  // -1: PDT_WGRAD_WIN64 / work-size rule, 0 off, 2 whenever the geometry fits
+
 // all-taps-per-workgroup weight gradient (conv_wgrad_win.hip): mode 0 = 3x3-style convs with C, N % 64 == 0;
 // mode 1 = the packed 3-channel stem (source pixel = 2 image pixels x 4 channels, tap = filter row)
 struct WinGeom {

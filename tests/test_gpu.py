@@ -107,6 +107,31 @@ def test_conv3x3_64ch_window_kernel_forced(kc, case):
     _assert_all_ok(kc, n)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8), (3, 13, 16), (2, 30, 24), (16, 56, 56), (300, 7, 8), (2, 3, 8), (5, 56, 40)])
+def test_wgrad_64ch_3x3_window_kernel_forced(shape):
+    """wgrad_win64.hip (TN product out of an LDS window, all nine taps per staged tile, persistent grid) on shapes the
+    work-size rule would leave to the per-tap kernel: partial last tiles (H % 4 != 0), more tiles than CUs, against
+    the fp32 reference and the per-tap kernel."""
+    from pytorch_distributed_training_amd import _C
+    from pytorch_distributed_training_amd.ops import native, reference
+
+    B, H, W = shape
+    torch.manual_seed(2)
+    mk = lambda: torch.randn(B, 64, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x, dy = mk(), mk()
+    try:
+        _C.set_wgrad_win64_mode(0)
+        dw0 = native.conv2d_wgrad(dy, x, (64, 64, 3, 3), 1, 1)
+        _C.set_wgrad_win64_mode(2)
+        dw1 = native.conv2d_wgrad(dy, x, (64, 64, 3, 3), 1, 1)
+    finally:
+        _C.set_wgrad_win64_mode(-1)
+    ref = reference.conv2d_wgrad(dy.float(), x.float(), (64, 64, 3, 3), 1, 1)
+    scale = ref.abs().max()
+    assert (dw1.float() - ref).abs().max() <= 5e-3 * scale
+    assert (dw1.float() - dw0.float()).abs().max() <= 5e-3 * scale
+
+
 @pytest.mark.parametrize("case,splits", [
     ((3, 128, 21, 21, 128, 3, 1, 1), 7), ((5, 256, 9, 9, 1024, 1, 1, 0), 5), ((2, 64, 30, 30, 64, 3, 1, 1), 13),
     ((3, 64, 23, 23, 128, 1, 1, 0), 9), ((3, 128, 20, 20, 64, 3, 2, 1), 4), ((2, 512, 7, 7, 512, 3, 1, 1), 3),
