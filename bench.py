@@ -39,12 +39,12 @@ def main(argv=None) -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    # per-GPU batch sized for 288 GB HBM3E: ~125 GB of bf16 activations at 1280 for ResNet-50 at 224x224; every conv
-    # launch has >12 rounds of tiles per CU (no tail effect) and the gradient all-reduce is <2 % of the step.
-    # Larger batches run too (activations beyond one 2 GiB buffer descriptor are launched in batch chunks, the
-    # memory model allows ~2.7k): 13.7k img/s at 1280, 13.9k at 2048 (default, ~200 GB), 14.0k at 2560, see
-    # profiles/r2_batch_sweep.md.
-    ap.add_argument("--batch_size", type=int, default=2048,
+    # per-GPU batch sized for 288 GB HBM3E: a ResNet-50 step at 224x224 holds ~41 MiB of bf16 activations per image
+    # (105 GiB at the default 2560, measured peak).  Activations beyond one 2 GiB buffer descriptor are launched in
+    # equal batch chunks; 2560 = two chunks of 1280 for the widest layers is the measured optimum (end of round 2:
+    # 14.7k img/s at 1280, 14.8k at 2048, 15.0k at 2304, 15.1-15.2k at 2560, 14.8k at 3072, 14.6-14.7k at 4096 / 5120);
+    # every conv launch has >12 rounds of tiles per CU and the gradient all-reduce is <1 % of the step.
+    ap.add_argument("--batch_size", type=int, default=2560,
                     help="per-GPU batch; 0 = size it from the memory model (utils/memory.py)")
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--image_size", type=int, default=224)

@@ -40,8 +40,12 @@ void set_activation_window(int64_t bytes) {
 long chunk_images(long B, long bytes_per_image) {
     TORCH_CHECK(bytes_per_image <= g_window_bytes, "one image of ", bytes_per_image,
                 " bytes exceeds the buffer-descriptor window of ", g_window_bytes, " bytes");
-    const long per = g_window_bytes / std::max<long>(bytes_per_image, 1);
-    return std::max<long>(1, std::min(per, B));
+    const long fit = std::max<long>(1, g_window_bytes / std::max<long>(bytes_per_image, 1));
+    if (fit >= B) return std::max<long>(1, B);
+    // equal chunks: 2048 images of a layer that fits 1337 per window run as 1024 + 1024, not 1337 + 711 (a short
+    // last chunk pays the per-launch ramp and tail of a full one)
+    const long chunks = (B + fit - 1) / fit;
+    return (B + chunks - 1) / chunks;
 }
 inline const char* at_image(const void* p, long b0, long bytes_per_image) {
     return p ? static_cast<const char*>(p) + b0 * bytes_per_image : nullptr;
