@@ -31,6 +31,7 @@ namespace {
 
 constexpr int WR = 4;
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct WgWin64Args {
     const void* dy;  // [B][H][W][64]
@@ -53,6 +54,9 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// STEPS: pixel steps per tile (W / 8) known at compile time -> the step loop is unrolled and every fragment address
+// of a tile is a per-lane constant (one v_add per read); 0 = any W, addresses computed per step
+template <int STEPS>
 __global__ __launch_bounds__(256, 1) void k_wgrad_win64(const WgWin64Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -61,16 +65,55 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_win64(const WgWin64Args a) {
     const uint32_t lds0 = lds_address(smem);
     const uint32_t dy_part = (uint32_t)a.W * (WR * 128u);
     const uint32_t buf_bytes = dy_part + (uint32_t)a.wpw * 4096u;
-    const int steps = a.W >> 3;  // WR * W / 32
+    const int steps = STEPS ? STEPS : a.W >> 3;  // WR * W / 32
 
     // ---- staging.  A piece is 8 pixels x 128 B; lane l fills (pixel l / 8, 16-B position l % 8) with the logical
     // chunk (l % 8) ^ (pixel index & 2)
     const int prow = lane >> 3, ppos = lane & 7;
+    // The source offset of a piece relative to the tile's first pixel does not depend on the tile (only whether its
+    // image row exists does): with the piece counts known at compile time they are per-lane constants, and a tile's
+    // staging costs 4 vector instructions per piece instead of ~25 (divisions, halo tests) -- measured: the address
+    // arithmetic of 18 pieces per wave and tile was a quarter of the tile's time.
+    constexpr int DPW = STEPS;                                   // W / 8 pieces of dy rows per wave
+    constexpr int WPW = STEPS ? ((WR + 2) * (STEPS * 8 + 2) * 128 + 4095) / 4096 : 1;
+    uint32_t drel[STEPS ? DPW : 1], xrel[WPW];
+    int drow[STEPS ? DPW : 1], xwr[WPW];
+    if constexpr (STEPS > 0) {
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const int p = wave + 4 * i, px = p * 8 + prow;
+            drel[i] = (uint32_t)px * 128u + (uint32_t)((ppos ^ swz(px)) << 4);
+            drow[i] = (int)fdiv((uint32_t)(p * 8), a.div_w);
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int p = wave + 4 * i, wp = p * 8 + prow;
+            const int wr = (int)fdiv((uint32_t)wp, a.div_w2), wc = wp - wr * a.W2;
+            const bool ok = wr < WR + 2 && (unsigned)(wc - 1) < (unsigned)a.W;
+            xrel[i] = (uint32_t)(((wr - 1) * a.W + wc - 1) * 128) + (uint32_t)((ppos ^ swz(wp)) << 4);
+            xwr[i] = ok ? wr : (1 << 24);  // (fails every row test)
+        }
+    }
     auto issue = [&](int tile, int buf) {
         const int b = tile / a.row_tiles, rt = tile - b * a.row_tiles;
         const int oh0 = rt * WR;
         const uint32_t l0 = lds0 + (uint32_t)buf * buf_bytes;
         const uint32_t img = (uint32_t)(b * a.H) * (uint32_t)a.W;  // pixel index of the image
+        if constexpr (STEPS > 0) {
+            const uint32_t tbase = (img + (uint32_t)(oh0 * a.W)) * 128u;
+#pragma unroll
+            for (int i = 0; i < DPW; ++i) {
+                const uint32_t piece = (uint32_t)(wave + 4 * i) * 1024u;
+                lds_dma16(rs_dy, oh0 + drow[i] < a.H ? tbase + drel[i] : kOOB, __builtin_amdgcn_readfirstlane(l0 + piece));
+            }
+#pragma unroll
+            for (int i = 0; i < WPW; ++i) {
+                const uint32_t piece = (uint32_t)(wave + 4 * i) * 1024u;
+                const bool live = (unsigned)(oh0 - 1 + xwr[i]) < (unsigned)a.H;
+                lds_dma16(rs_x, live ? tbase + xrel[i] : kOOB, __builtin_amdgcn_readfirstlane(l0 + dy_part + piece));
+            }
+            return;
+        }
         for (int i = 0; i < a.dpw; ++i) {
             const int p = wave + 4 * i;
             const int px = p * 8 + prow;
@@ -105,8 +148,13 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_win64(const WgWin64Args a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[ng][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // x fragments: the three taps of a filter row read pixels p .. p+7, p+1 .. p+8, p+2 .. p+9 of the same window row.
+    // One set of reads covers p .. p+11 (three transposed reads of 4 pixels); tap dw = 0 is dwords 0-3, dw = 2 dwords
+    // 1-4, dw = 1 four v_alignbit across neighbours: 9 reads per step instead of 18.
     struct Frags {
-        bf16x8 d[4], x[9];
+        bf16x8 d[4];
+        u32x4 xa[3];   // per filter row: pixels 0-7 (two bf16 per dword)
+        uint32_t xe[3];  // pixels 8, 9
     };
     // pixel-step bookkeeping of a fragment set: the 8 pixels of a lane group lie in one image row (W % 8 == 0)
     auto window_pixel = [&](int st) {
@@ -114,24 +162,46 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_win64(const WgWin64Args a) {
         const int r = (int)fdiv((uint32_t)px0, a.div_w), col = px0 - r * a.W;
         return r * a.W2 + col + qq;  // under tap (0, 0)
     };
-    auto load_x = [&](const char* buf, int wp0, int t) {
-        const int wp = wp0 + (t / 3) * a.W2 + (t % 3);
-        return tr_pair(buf + dy_part + (uint32_t)wp * 128u + ((xchunk ^ (uint32_t)swz(wp)) << 4) + xlow);
+    auto x_offset = [&](int wp0, int dh) {
+        const int wp = wp0 + dh * a.W2;
+        return dy_part + (uint32_t)wp * 128u + ((xchunk ^ (uint32_t)(wp & 2)) << 4) + xlow;
     };
-    // One 32-pixel step: the 36 MFMAs of `cur`, with the 26 fragment reads of the NEXT step (`nxt`, pixel step stn)
-    // issued in between, a tap's worth per group of four MFMAs.  The order is pinned (sched_barrier): with one wave
-    // per SIMD nothing else hides the LDS latency, and at most ~8 reads are in flight beyond the ones the next MFMA
-    // group waits for (the counter behind s_waitcnt lgkmcnt only goes to 15).
+    uint32_t xoff[STEPS ? STEPS : 1][3];
+    if constexpr (STEPS > 0) {
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) xoff[st][dh] = x_offset(window_pixel(st), dh);
+    }
+    auto load_x = [&](Frags& f, const char* buf, int st, int dh) {
+        const char* p = buf + (STEPS ? xoff[STEPS ? st : 0][dh] : x_offset(window_pixel(st), dh));
+        f.xa[dh] = __builtin_bit_cast(u32x4, tr_pair(p));
+        const bf16x4 e = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + 1024));  // pixels + 8 .. + 11
+        f.xe[dh] = __builtin_bit_cast(u32x2, e)[0];
+    };
+    auto x_frag = [&](const Frags& f, int t) {
+        const u32x4 v = f.xa[t / 3];
+        const uint32_t e = f.xe[t / 3];
+        u32x4 o;
+        if (t % 3 == 0) o = v;
+        else if (t % 3 == 2) o = u32x4{v[1], v[2], v[3], e};
+        else o = u32x4{__builtin_amdgcn_alignbit(v[1], v[0], 16), __builtin_amdgcn_alignbit(v[2], v[1], 16),
+                       __builtin_amdgcn_alignbit(v[3], v[2], 16), __builtin_amdgcn_alignbit(e, v[3], 16)};
+        return __builtin_bit_cast(bf16x8, o);
+    };
+    // One 32-pixel step: the 36 MFMAs of `cur`, with the 17 fragment reads of the NEXT step (`nxt`, pixel step stn)
+    // issued in between.  The order is pinned (sched_barrier): with one wave per SIMD nothing else hides the LDS
+    // latency, and the counter behind s_waitcnt lgkmcnt only goes to 15.
     auto step = [&](const Frags& cur, Frags& nxt, const char* buf, int stn) {
         const char* dp = buf + (uint32_t)stn * 4096u;
-        const int wp0 = window_pixel(stn);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (t < 4) nxt.d[t] = tr_pair(dp + a_off[t]);
-            nxt.x[t] = load_x(buf, wp0, t);
+            if (t >= 4 && t < 7) load_x(nxt, buf, stn, t - 4);
+            const bf16x8 xf = x_frag(cur, t);
 #pragma unroll
             for (int ng = 0; ng < 4; ++ng)
-                acc[ng][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.d[ng], cur.x[t], acc[ng][t], 0, 0, 0);
+                acc[ng][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.d[ng], xf, acc[ng][t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -146,18 +216,23 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_win64(const WgWin64Args a) {
         if (next < a.tiles) issue(next, buf ^ 1);
         const char* base = smem + (size_t)buf * buf_bytes;
         Frags fa, fb;
-        {
-            const int wp0 = window_pixel(0);
 #pragma unroll
-            for (int ng = 0; ng < 4; ++ng) fa.d[ng] = tr_pair(base + a_off[ng]);
+        for (int ng = 0; ng < 4; ++ng) fa.d[ng] = tr_pair(base + a_off[ng]);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) fa.x[t] = load_x(base, wp0, t);
-        }
+        for (int dh = 0; dh < 3; ++dh) load_x(fa, base, 0, dh);
         // two steps per trip, the fragment sets swap roles (no register copies); past the last step the prefetch
         // re-reads the last one (in range, unused)
-        for (int st = 0; st < steps; st += 2) {
-            step(fa, fb, base, min(st + 1, steps - 1));
-            if (st + 1 < steps) step(fb, fa, base, min(st + 2, steps - 1));
+        if constexpr (STEPS > 0) {
+#pragma unroll
+            for (int st = 0; st < STEPS; st += 2) {
+                step(fa, fb, base, st + 1 < STEPS ? st + 1 : STEPS - 1);
+                if (st + 1 < STEPS) step(fb, fa, base, st + 2 < STEPS ? st + 2 : STEPS - 1);
+            }
+        } else {
+            for (int st = 0; st < steps; st += 2) {
+                step(fa, fb, base, min(st + 1, steps - 1));
+                if (st + 1 < steps) step(fb, fa, base, min(st + 2, steps - 1));
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -228,11 +303,18 @@ void launch_wgrad_win64(const void* dy, const void* x, float* slab, int B, int H
     const int lds = (int)wg64_lds(W);
     static int attr_lds = 0;
     if (lds > attr_lds) {
-        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_win64),
+        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_win64<0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_win64<7>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(k_wgrad_win64, dim3(wgrad_win64_grid(B, H)), dim3(256), lds, s, a);
+    static const bool unrolled = [] {
+        const char* e = std::getenv("PDT_WGRAD_WIN64_UNROLL");
+        return !(e && std::atoi(e) == 0);
+    }();
+    if (W == 56 && unrolled) hipLaunchKernelGGL(k_wgrad_win64<7>, dim3(wgrad_win64_grid(B, H)), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_wgrad_win64<0>, dim3(wgrad_win64_grid(B, H)), dim3(256), lds, s, a);
 }
 
 }  // namespace pdt
