@@ -164,6 +164,49 @@ def main() -> int:
     n_tot = big.numel() / c
     out["syncbn_big_var_rel_err"] = float(((bn_big.running_var.double() * (n_tot - 1) / n_tot - var64) / var64).abs().max())
 
+    # 4b. a bottleneck net with downsample branches under SyncBN: the block-output BN and the downsample BN share one
+    # pass over their gradient (bn_bwd_elemt2) and BOTH exchange their sums inside the table kernels
+    import copy
+
+    import pytorch_distributed_training_amd.models.resnet as R
+    from pytorch_distributed_training_amd.ops import native
+    from pytorch_distributed_training_amd.parallel import ParamArena
+
+    torch.manual_seed(11)
+    net_ref = R.ResNet(R.Bottleneck, [1, 1, 1, 1], num_classes=10).to(dev)
+    net_sync = pnn.convert_sync_batchnorm(copy.deepcopy(net_ref))
+    arenas = [ParamArena(net_ref), ParamArena(net_sync)]
+    for ar in arenas:
+        ar.attach_lowp(torch.bfloat16)
+    nb = 8
+    gen3 = torch.Generator().manual_seed(13)
+    xf = torch.randn(nb * world, 3, 64, 64, generator=gen3).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    sl2 = slice(rank * nb, (rank + 1) * nb)
+    calls = []
+    orig2 = native.bn_bwd_elemt2
+    native.bn_bwd_elemt2 = lambda *a_, **k_: (calls.append(k_.get("ipc") is not None), orig2(*a_, **k_))[1]
+    try:
+        o_ref = net_ref(xf)
+        o_ref.float().square().sum().backward()
+        n_ref_calls = len(calls)
+        o_sync = net_sync(xf[sl2].contiguous(memory_format=torch.channels_last))
+        o_sync.float().square().sum().backward()
+    finally:
+        native.bn_bwd_elemt2 = orig2
+    torch.cuda.synchronize()
+    out["dual_calls"] = [n_ref_calls, len(calls) - n_ref_calls, all(calls[n_ref_calls:]), any(calls[:n_ref_calls])]
+    out["dual_out_err"] = float((o_sync.float() - o_ref[sl2].float()).abs().max() / o_ref.float().abs().max())
+    # weight gradients: the ranks' local gradients add up to the single-process ones (what DDP's all-reduce does)
+    cos = 1.0
+    for (n1, p1), (_, p2) in zip(net_ref.named_parameters(), net_sync.named_parameters()):
+        if not (n1.endswith("conv1.weight") or n1.endswith("downsample.0.weight") or n1 == "fc.weight"):
+            continue
+        g2 = p2.grad.detach().float().cpu()
+        tdist.all_reduce(g2)
+        g1 = p1.grad.detach().float().cpu().flatten()
+        cos = min(cos, float(torch.dot(g2.flatten(), g1) / (g2.norm() * g1.norm() + 1e-12)))
+    out["dual_dw_cos"] = cos
+
     # 5. a peer that never arrives: the kernel gives up after the limit, the flag is raised, the next call refuses
     torch.cuda.synchronize()
     tdist.barrier()

@@ -711,6 +711,9 @@ def test_ipc_small_allreduce_two_processes_on_one_gpu(tmp_path):
         for tag, (k_ref, k_sync) in o["kernel_names"].items():
             assert sorted(k_ref) == sorted(k_sync) and len(k_ref) >= 4, (tag, k_ref, k_sync)
         assert o["syncbn_big_mean_err"] < 1e-4 and o["syncbn_big_var_rel_err"] < 2e-3, o  # (fp32 partial rows inside a tile)
+        # bottleneck net: 4 downsample blocks, dual BN backward with in-kernel exchange in the SyncBN run only
+        assert o["dual_calls"] == [4, 4, True, False], o
+        assert o["dual_out_err"] < 0.05 and o["dual_dw_cos"] > 0.9, o
     r0 = [o for o in outs if o["rank"] == 0][0]
     assert r0["timed_out"] and r0["refused_after_timeout"], r0
     print("ipc all-reduce us/op:", r0["ipc_us"], " gloo-staged group us/op:", r0["group_us"])
