@@ -16,10 +16,13 @@
 // bank period).  The 32-B granule index is therefore XORed with bit 1 of the pixel index on the way in (DMA source
 // swizzle): any 4 consecutive pixels land in 4 different granules.
 //
-// Measured at B = 1280, 56x56 (MI355X): 615 -> 365 us per launch (800 TFLOP/s).  Without the DMA of the following
-// tiles 280 us, with the DMA but two of the seven pixel steps 212 us (= the one read of both tensors at 5.5 TB/s):
-// a step costs ~1150 cycles against 576 of MFMA issue, i.e. the transposing reads (26 per step and wave) bound it,
-// and the staging is not fully hidden behind them.
+// Measured at B = 1280, 56x56 (MI355X): 615 -> 308 us per launch (960 TFLOP/s incl. the slab reduction).  Steps on the
+// way: first version 395 us; pinned read / MFMA interleave with swapped fragment sets instead of register copies 365;
+// step loop unrolled with per-lane constant addresses 350; per-lane constant DMA source offsets 308 (the address
+// arithmetic of the 18 staging pieces per wave and tile -- divisions, halo tests -- had been a quarter of a tile's
+// time).  Sharing the x reads between the taps of a filter row changed nothing: a 32-pixel step runs its 36 MFMAs in
+// ~970 cycles, which is the ~1.45 PFLOP/s the matrix pipe sustains in every kernel here, not the LDS.  Without any
+// staging the kernel takes 280 us; the one read of both tensors at 5.5 TB/s is 210 us.
 #include <algorithm>
 #include <cstdlib>
 
