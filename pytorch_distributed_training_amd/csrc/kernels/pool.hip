@@ -146,6 +146,64 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const bf16* __restrict__ dy
     }
 }
 
+// Even H and W: a thread owns a 2x2 block of full-resolution pixels (h = 2i + a, w = 2j + b) of one channel group.
+// Exactly the four windows (i + da, j + dc) touch it, and each (window, tap) pair lands on one known pixel of the
+// block: window (0,0) taps 4 / 5 / 7 / 8 -> pixels (0,0) / (0,1) / (1,0) / (1,1), window (0,1) taps 3 / 6 -> (0,1) /
+// (1,1), window (1,0) taps 1 / 2 -> (1,0) / (1,1), window (1,1) tap 0 -> (1,1).  Four window loads and nine compares
+// per channel for four pixels, where the per-pixel kernel above loads nine windows and compares sixteen times (it was
+// instruction-bound, see its comment); the sums run in the same order, so the results are bit-identical.
+__global__ __launch_bounds__(256) void k_maxpool_bwd_2x2(const bf16* __restrict__ dy, const uint8_t* __restrict__ argmax,
+                                                         bf16* __restrict__ dx, int B, int H, int W, int C, int Ho,
+                                                         int Wo, PoolDiv dv /* .w: W / 2, .h: H / 2 */) {
+    const uint32_t G = (uint32_t)C >> 3, R = 256u / G;
+    const uint32_t cg = threadIdx.x % G, rl = threadIdx.x / G;
+    const uint32_t Hb = (uint32_t)H >> 1, Wb = (uint32_t)W >> 1;
+    const uint32_t p = xcd_grouped_block() * R + rl;
+    if (p >= (uint32_t)B * Hb * Wb) return;
+    const uint32_t t = fdiv(p, dv.w);
+    const int j = (int)(p - t * Wb);
+    const uint32_t bb = fdiv(t, dv.h);
+    const int i = (int)(t - bb * Hb);
+    const int b = (int)bb;
+    bf16x8 gy[4];
+    uint2 am[4];
+#pragma unroll
+    for (int da = 0; da < 2; ++da)
+#pragma unroll
+        for (int dc = 0; dc < 2; ++dc) {
+            const int ho = i + da, wo = j + dc;
+            const bool ok = ho < Ho && wo < Wo;
+            const uint32_t off = (uint32_t)(((b * Ho + min(ho, Ho - 1)) * Wo + min(wo, Wo - 1)) * C) + cg * 8;
+            gy[da * 2 + dc] = ld8(dy + off);
+            const uint2 a = *reinterpret_cast<const uint2*>(argmax + off);
+            am[da * 2 + dc] = ok ? a : make_uint2(0xffffffffu, 0xffffffffu);  // (no tap code matches 0xff)
+        }
+    bf16x8 o[4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int sh = 8 * (k & 3);
+        uint32_t c[4];
+        float g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c[q] = ((k < 4 ? am[q].x : am[q].y) >> sh) & 0xffu;
+            g[q] = (float)gy[q][k];
+        }
+        o[0][k] = (bf16)(c[0] == 4u ? g[0] : 0.f);
+        o[1][k] = (bf16)((c[0] == 5u ? g[0] : 0.f) + (c[1] == 3u ? g[1] : 0.f));
+        o[2][k] = (bf16)((c[0] == 7u ? g[0] : 0.f) + (c[2] == 1u ? g[2] : 0.f));
+        o[3][k] = (bf16)((((c[0] == 8u ? g[0] : 0.f) + (c[1] == 6u ? g[1] : 0.f)) + (c[2] == 2u ? g[2] : 0.f)) +
+                         (c[3] == 0u ? g[3] : 0.f));
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t pix = (uint32_t)((b * H + 2 * i + a) * W + 2 * j + e);
+            *reinterpret_cast<bf16x8*>(dx + pix * (uint32_t)C + cg * 8) = o[a * 2 + e];
+        }
+}
+
 // y[b][c] = mean over HW; thread = (b, 8 channels)
 __global__ __launch_bounds__(256) void k_avgpool_fwd(const bf16* __restrict__ x, bf16* __restrict__ y, int B, int HW,
                                                      int C) {
@@ -217,6 +275,18 @@ void launch_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, in
     if (256 % (C >> 3) != 0) {
         fprintf(stderr, "maxpool bwd: C / 8 must divide 256 (got C = %d)\n", C);
         abort();
+    }
+    static const bool blocked = [] {
+        const char* e = getenv("PDT_POOL_BWD_2X2");
+        return !(e && e[0] == '0');
+    }();
+    if (blocked && H % 2 == 0 && W % 2 == 0 && Ho == H / 2 && Wo == W / 2) {
+        const PoolDiv d2{make_fastdiv((uint32_t)(C >> 3)), make_fastdiv((uint32_t)(W / 2)), make_fastdiv((uint32_t)(H / 2))};
+        const long per = 256 / (C >> 3);
+        const long nb = ((long)B * (H / 2) * (W / 2) + per - 1) / per;
+        hipLaunchKernelGGL(k_maxpool_bwd_2x2, dim3((unsigned)nb), dim3(256), 0, s, (const bf16*)dy, argmax, (bf16*)dx, B,
+                           H, W, C, Ho, Wo, d2);
+        return;
     }
     const long per_block = (long)kPoolUnroll * (256 / (C >> 3));
     const long blocks = ((long)B * H * W + per_block - 1) / per_block;
