@@ -496,6 +496,11 @@ def check_optim(time_it):
         x = torch.rand(3, 3, 224, 224, device=DEV)
         y = native.nchw_to_nhwc_lowp(x)
         record("to_nhwc_bf16 f32 224x224", rel_err(y, reference.nchw_to_nhwc_lowp(x)) == 0, rel_err(y, reference.nchw_to_nhwc_lowp(x)))
+        for shp in ((2, 3, 15, 17), (2, 5, 9, 13), (130, 3, 64, 64)):  # LDS-tile kernel (odd sizes, C != 3); > 2^16 groups
+            x = torch.rand(*shp, device=DEV) * 4 - 2
+            y = native.nchw_to_nhwc_lowp(x, torch.bfloat16, 0.5)
+            yr = reference.nchw_to_nhwc_lowp(x, torch.bfloat16, 0.5)
+            record(f"to_nhwc_bf16 f32 {shp}", rel_err(y, yr) == 0, rel_err(y, yr))
         u = torch.randint(0, 256, (4, 32, 32, 3), device=DEV, dtype=torch.uint8)
         y = native.nchw_to_nhwc_lowp(u, torch.bfloat16, 1 / 255.0)
         record("to_nhwc_bf16 u8", rel_err(y, reference.nchw_to_nhwc_lowp(u, torch.bfloat16, 1 / 255.0)) < 1e-2,
