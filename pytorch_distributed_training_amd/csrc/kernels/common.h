@@ -75,6 +75,20 @@ __device__ __forceinline__ void lds_dma16(i32x4 rsrc, uint32_t byte_off, uint32_
         : "memory");
 }
 
+// the same for an operand that is streamed through once (non-temporal hint, see st_stream)
+__device__ __forceinline__ void lds_dma16_stream(i32x4 rsrc, uint32_t byte_off, uint32_t lds_addr_uniform) {
+#ifdef PDT_PLAIN_LDST
+    lds_dma16(rsrc, byte_off, lds_addr_uniform);
+#else
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(byte_off), "s"(rsrc), "s"(lds_addr_uniform)
+        : "memory");
+#endif
+}
+
 // same with a scalar byte offset added to every lane's address (buffer SOFFSET): a K loop that only moves along the
 // channel axis keeps its per-lane offsets and advances one SGPR
 __device__ __forceinline__ void lds_dma16s(i32x4 rsrc, uint32_t byte_off, uint32_t soffset_uniform,
@@ -86,6 +100,18 @@ __device__ __forceinline__ void lds_dma16s(i32x4 rsrc, uint32_t byte_off, uint32
         : "v"(byte_off), "s"(rsrc), "s"(lds_addr_uniform), "s"(soffset_uniform)
         : "memory");
 }
+
+// Streams that are written once and read much later (activations, gigabytes per layer) go to memory with the
+// non-temporal hint: measured +10 % on a streaming add (bench/micro/hbm_nt.hip).  -DPDT_PLAIN_LDST builds without.
+#ifdef PDT_PLAIN_LDST
+constexpr int kAuxStream = 0;
+__device__ __forceinline__ void st_stream(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+__device__ __forceinline__ u32x4 ld_stream(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+#else
+constexpr int kAuxStream = 2;  // buffer instructions: the nt bit of the cache policy
+__device__ __forceinline__ void st_stream(void* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
+__device__ __forceinline__ u32x4 ld_stream(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+#endif
 
 constexpr uint32_t kOOB = 0x80000000u;  // > any legal byte offset (tensors are < 2 GiB, checked on the host)
 

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                     r1[k] += gg * ((float)xv[k] - mu[k]) * is[k];
                 }
             }
-            *reinterpret_cast<bf16x8*>(y + pix * g.N + ncol) = v;
+            st_stream(y + pix * g.N + ncol, __builtin_bit_cast(u32x4, v));
         }
     }
     if (bnr) {

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_stem_pack_x(const uint32_t* __restrict_
         v[2] = (d1 >> 16) | (d2 << 16);
         v[3] = d2 >> 16;
     }
-    xp[i] = v;
+    st_stream(xp + i, v);
 }
 
 __global__ __launch_bounds__(256) void k_stem_pack_w(const bf16* __restrict__ w, bf16* __restrict__ wp, int total) {

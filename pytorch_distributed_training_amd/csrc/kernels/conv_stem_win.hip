@@ -122,6 +122,8 @@ __global__ __launch_bounds__(SW_THREADS, 1) void k_stem_win(const StemWinArgs a)
                         q[k] += v * v;
                     }
                 bf16* dst = reinterpret_cast<bf16*>(a.y) + ((size_t)(b * a.Ho + oh) * a.Wo + fc * 16 + px) * 64 + 16 * g;
+                // (plain stores: a lane writes 32 B of a 128-B pixel and the L2 merges the four lane groups into full
+                // lines; with the non-temporal hint the kernel took 1.5x as long)
                 *reinterpret_cast<bf16x8*>(dst) = o[0];
                 *reinterpret_cast<bf16x8*>(dst + 8) = o[1];
             } else {
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void k_stem_wgrad_win(const StemWgradArgs a
         for (int i = 0; i < a.dpw; ++i) {
             const int p = wave + 4 * i;              // (p & 1 == wave & 1: the key above)
             const bool live = oh0 + (p * 8) / a.Wo < a.Ho;  // rows past the image contribute zeros
-            lds_dma16(rs_dy, live ? dbase + (uint32_t)p * 1024u : kOOB, __builtin_amdgcn_readfirstlane(l0 + (uint32_t)p * 1024u));
+            lds_dma16_stream(rs_dy, live ? dbase + (uint32_t)p * 1024u : kOOB, __builtin_amdgcn_readfirstlane(l0 + (uint32_t)p * 1024u));
         }
         const uint32_t xbase = (uint32_t)(b * a.Hp + 2 * oh0) * row_bytes + (uint32_t)lane * 16u;
         for (int i = 0; i < a.wpw; ++i) {

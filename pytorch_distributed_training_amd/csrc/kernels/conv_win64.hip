@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_win64(const Win64Args a) {
                 csq[k] += f * f;
             }
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, in ? (uint32_t)(pix * 128 + och * 16) : kOOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, in ? (uint32_t)(pix * 128 + och * 16) : kOOB, 0, kAuxStream);
     };
 
     int tile = blockIdx.x;

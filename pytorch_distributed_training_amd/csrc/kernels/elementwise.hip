@@ -240,8 +240,8 @@ __global__ __launch_bounds__(256) void k_nchw3_f32_to_nhwc_bf16(const float* __r
     float v[3][8];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(p + (long)c * HW);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(p + (long)c * HW + 4);
+        const f32x4 lo = __builtin_bit_cast(f32x4, ld_stream(p + (long)c * HW));
+        const f32x4 hi = __builtin_bit_cast(f32x4, ld_stream(p + (long)c * HW + 4));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             v[c][k] = lo[k] * scale;
@@ -252,9 +252,9 @@ __global__ __launch_bounds__(256) void k_nchw3_f32_to_nhwc_bf16(const float* __r
 #pragma unroll
     for (int e = 0; e < 24; ++e) o[e >> 3][e & 7] = (bf16)v[e % 3][e / 3];
     bf16x8* out = reinterpret_cast<bf16x8*>(dst + ((long)b * HW + (long)g * 8) * 3);
-    out[0] = o[0];
-    out[1] = o[1];
-    out[2] = o[2];
+    st_stream(out, __builtin_bit_cast(u32x4, o[0]));
+    st_stream(out + 1, __builtin_bit_cast(u32x4, o[1]));
+    st_stream(out + 2, __builtin_bit_cast(u32x4, o[2]));
 }
 
 // u8 NHWC -> bf16 NHWC (pure elementwise)

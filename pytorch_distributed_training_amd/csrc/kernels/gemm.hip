@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                     const int lrow = (pb + p) * 16 + orow;
                     bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + lrow * OPITCH + och * 16);
                     if (ACT)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, coff[p], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, coff[p], 0, kAuxStream);
                     if (ACT) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = (bf16)gelu_f((float)v[k]);
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                             }
                         }
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, coff[p], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, coff[p], 0, kAuxStream);
                 }
             }
             if (hh == 0) {

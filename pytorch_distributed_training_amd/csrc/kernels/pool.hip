@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const bf16* __restrict__ dy
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (bf16)acc[k];
-        *reinterpret_cast<bf16x8*>(dx + p * (uint32_t)C + cg * 8) = o;
+        st_stream(dx + p * (uint32_t)C + cg * 8, __builtin_bit_cast(u32x4, o));
     }
 }
 
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd_2x2(const bf16* __restrict_
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const uint32_t pix = (uint32_t)((b * H + 2 * i + a) * W + 2 * j + e);
-            *reinterpret_cast<bf16x8*>(dx + pix * (uint32_t)C + cg * 8) = o[a * 2 + e];
+            st_stream(dx + pix * (uint32_t)C + cg * 8, __builtin_bit_cast(u32x4, o[a * 2 + e]));
         }
 }
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_win64(const WgWin64Args a) {
 #pragma unroll
             for (int i = 0; i < DPW; ++i) {
                 const uint32_t piece = (uint32_t)(wave + 4 * i) * 1024u;
-                lds_dma16(rs_dy, oh0 + drow[i] < a.H ? tbase + drel[i] : kOOB, __builtin_amdgcn_readfirstlane(l0 + piece));
+                lds_dma16_stream(rs_dy, oh0 + drow[i] < a.H ? tbase + drel[i] : kOOB, __builtin_amdgcn_readfirstlane(l0 + piece));
             }
 #pragma unroll
             for (int i = 0; i < WPW; ++i) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_win64(const WgWin64Args a) {
             const int px = p * 8 + prow;
             const bool live = oh0 + (int)fdiv((uint32_t)(p * 8), a.div_w) < a.H;  // rows past the image: zeros
             const uint32_t off = (img + (uint32_t)(oh0 * a.W + px)) * 128u + (uint32_t)((ppos ^ swz(px)) << 4);
-            lds_dma16(rs_dy, live ? off : kOOB, __builtin_amdgcn_readfirstlane(l0 + (uint32_t)p * 1024u));
+            lds_dma16_stream(rs_dy, live ? off : kOOB, __builtin_amdgcn_readfirstlane(l0 + (uint32_t)p * 1024u));
         }
         for (int i = 0; i < a.wpw; ++i) {
             const int p = wave + 4 * i;
