@@ -46,6 +46,15 @@ __device__ __forceinline__ bf16x8 buffer_load_bf16x8(__amdgpu_buffer_rsrc_t rsrc
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
     return __builtin_bit_cast(bf16x8, v);
 }
+// (an operand that is read exactly once: residual-gradient addends, BN inputs in the fused epilogues)
+__device__ __forceinline__ bf16x8 buffer_load_bf16x8_stream(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+#ifdef PDT_PLAIN_LDST
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+#else
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 2);
+#endif
+    return __builtin_bit_cast(bf16x8, v);
+}
 // ---- LDS-DMA (buffer_load_dwordx4 ... lds): 16 B per lane from a per-lane buffer offset straight into LDS at
 // wave-uniform address + 16 * lane, no VGPR destination.  Issued through inline asm on purpose: for the builtin
 // form the compiler cannot prove that a later ds_read does not alias the in-flight DMA and inserts its own
@@ -99,6 +108,20 @@ __device__ __forceinline__ void lds_dma16s(i32x4 rsrc, uint32_t byte_off, uint32
         : "=&s"(keep)
         : "v"(byte_off), "s"(rsrc), "s"(lds_addr_uniform), "s"(soffset_uniform)
         : "memory");
+}
+
+__device__ __forceinline__ void lds_dma16s_stream(i32x4 rsrc, uint32_t byte_off, uint32_t soffset_uniform,
+                                                  uint32_t lds_addr_uniform) {
+#ifdef PDT_PLAIN_LDST
+    lds_dma16s(rsrc, byte_off, soffset_uniform, lds_addr_uniform);
+#else
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen nt lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(byte_off), "s"(rsrc), "s"(lds_addr_uniform), "s"(soffset_uniform)
+        : "memory");
+#endif
 }
 
 // Streams that are written once and read much later (activations, gigabytes per layer) go to memory with the

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
             }
             if (m < M && ncol < g.N) {
                 if (bnr) {
-                    bx[p] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.bnr_x) + m * g.N + ncol);
+                    bx[p] = __builtin_bit_cast(bf16x8, ld_stream(static_cast<const bf16*>(g.bnr_x) + m * g.N + ncol));
                     bbits[p] = g.bnr_mask[(m * g.N + ncol) >> 3];
                 }
                 if (has_add && g.addend_stride == 2) {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                         abits[p] = 0xffu;
                     }
                 } else if (has_add) {
-                    ad[p] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.addend) + m * g.N + ncol);
+                    ad[p] = __builtin_bit_cast(bf16x8, ld_stream(static_cast<const bf16*>(g.addend) + m * g.N + ncol));
                     abits[p] = g.addend_mask != nullptr ? g.addend_mask[(m * g.N + ncol) >> 3] : 0xffu;
                 }
             }
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                     for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)a[k]);
                 }
             } else if (g.addend != nullptr) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.addend) + pix * g.N + ncol);
+                const bf16x8 a = __builtin_bit_cast(bf16x8, ld_stream(static_cast<const bf16*>(g.addend) + pix * g.N + ncol));
                 const unsigned abits = g.addend_mask != nullptr ? g.addend_mask[(pix * g.N + ncol) >> 3] : 0xffu;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (((abits >> k) & 1u) ? (float)a[k] : 0.f));
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                     xv = bx[p];
                     bits = bbits[p];
                 } else {
-                    xv = *reinterpret_cast<const bf16x8*>(static_cast<const bf16*>(g.bnr_x) + pix * g.N + ncol);
+                    xv = __builtin_bit_cast(bf16x8, ld_stream(static_cast<const bf16*>(g.bnr_x) + pix * g.N + ncol));
                     bits = g.bnr_mask[(pix * g.N + ncol) >> 3];
                 }
 #pragma unroll

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
             uint32_t v = isB ? vB[j] : vA[j];
             if (r >= rows || (j ? cut1 : cut0)) v = kOOB;
             if (TAPS && !isB && !((tapmask[h][j] >> ti) & 1u)) v = kOOB;
-            lds_dma16s(isB ? rb : ra, v, soff, dst + (uint32_t)(j * 1024));
+            if (!TAPS && !isB && a.a_stream) lds_dma16s_stream(ra, v, soff, dst + (uint32_t)(j * 1024));
+            else lds_dma16s(isB ? rb : ra, v, soff, dst + (uint32_t)(j * 1024));
         }
     };
 
@@ -355,14 +356,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                     for (int p = 0; p < PB; ++p) {
                         const int row = hh * 128 + (pb + p) * 16 + orow;
                         const uint32_t eo = col_ok ? (uint32_t)row * (uint32_t)(lde * 2) + (uint32_t)(ncol * 2) : kOOB;
-                        if (EXTRA != 0 || has_add) ev[p] = buffer_load_bf16x8(re, eo);
+                        if (EXTRA != 0 || has_add) ev[p] = buffer_load_bf16x8_stream(re, eo);
                         if (CONV == 2) {
                             const bool in = col_ok && row < orows_m;
                             abits[p] = has_add ? 0xffu : 0u;
                             if (has_amask) abits[p] = in ? amask[eo >> 4] : 0u;
                             bbits[p] = 0u;
                             if (bnr) {
-                                bx[p] = buffer_load_bf16x8(rx, eo);
+                                bx[p] = buffer_load_bf16x8_stream(rx, eo);
                                 bbits[p] = in ? bmask[eo >> 4] : 0u;
                             }
                         }
@@ -487,6 +488,7 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
     GemmArgs a = args;
     a.m_tiles = gemm_m_tiles(a.M);
     a.n_tiles = (a.N + BN - 1) / BN;
+    a.a_stream = a.n_tiles == 1 && a.ntaps == 0 ? 1 : 0;
     if (a.M <= 0 || a.N <= 0) return;
     // 32 tiles run together on one XCD: with many tile columns walk bands of 4 tile rows (4 A panels + 8 B panels
     // per K-step instead of 1 + 32)

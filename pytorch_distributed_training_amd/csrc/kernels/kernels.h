@@ -254,6 +254,7 @@ struct GemmArgs {
     // ntaps x (K / 64) tiles; tap t reads pixel (y + tap_dh, x + tap_dw) of the same image (zeros outside) and the
     // weight columns [tap_w * K, (tap_w + 1) * K) of B, whose rows are ldb = wtaps * K long.  ntaps == 0: plain GEMM.
     int ntaps, H, W;
+    int a_stream;  // (set by launch_gemm_nt) one tile column: A is read exactly once -> non-temporal DMA
     int32_t tap[9];  // (dh & 0xff) | (dw & 0xff) << 8 | wslot << 16
     FastDiv div_w, div_hw, div_kt;  // / W, / (H * W), / (K / 64)
     int m_tiles, n_tiles, group_m;  // filled by the launcher
