@@ -488,7 +488,13 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
     GemmArgs a = args;
     a.m_tiles = gemm_m_tiles(a.M);
     a.n_tiles = (a.N + BN - 1) / BN;
-    a.a_stream = a.n_tiles == 1 && a.ntaps == 0 ? 1 : 0;
+    // (K-tiles are 64 elements = whole 128-B lines.  The same hint on the implicit-GEMM kernel's 64-B K-steps LOST 2.7 %
+    // of the step: the second half of every line came from memory again.)  PDT_GEMM_A_STREAM=0: off.
+    static const bool a_stream_on = [] {
+        const char* e = getenv("PDT_GEMM_A_STREAM");
+        return !(e && e[0] == '0');
+    }();
+    a.a_stream = a_stream_on && a.n_tiles == 1 && a.ntaps == 0 ? 1 : 0;
     if (a.M <= 0 || a.N <= 0) return;
     // 32 tiles run together on one XCD: with many tile columns walk bands of 4 tile rows (4 A panels + 8 B panels
     // per K-step instead of 1 + 32)
