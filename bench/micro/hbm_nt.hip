@@ -70,5 +70,20 @@ int main(int argc, char** argv) {
         printf("U=2 plain              %.3f ms  %.2f TB/s\nU=2 nt loads + stores  %.3f ms  %.2f TB/s\n", t2[0], 3.0 * bytes / t2[0] / 1e9, t2[1],
                3.0 * bytes / t2[1] / 1e9);
     }
+    printf("U=8 nt loads + stores  %.3f ms  %.2f TB/s\n", run<3, 8>(a, b, c, n), 3.0 * bytes / run<3, 8>(a, b, c, n) / 1e9);
+    printf("U=1 nt loads + stores  %.3f ms  %.2f TB/s\n", run<3, 1>(a, b, c, n), 3.0 * bytes / run<3, 1>(a, b, c, n) / 1e9);
+    // relative placement of the three streams: b and c shifted by off and 2 * off bytes (all PyTorch blocks are 2 MiB
+    // aligned, i.e. every stream of a kernel starts on the same memory channel)
+    u32x4* big;
+    const long pad = 64L << 20;
+    if (hipMalloc(&big, 3 * bytes + 3 * pad) != hipSuccess) return 0;
+    const long offs[] = {0, 256, 4096, 65536, (1L << 20) + 4096, (8L << 20) + 65536 + 256};
+    for (long off : offs) {
+        const u32x4* a2 = big;
+        const u32x4* b2 = (const u32x4*)((const char*)big + bytes + pad + off);
+        u32x4* c2 = (u32x4*)((char*)big + 2 * (bytes + pad) + 2 * off);
+        const float t = run<3, 4>(a2, b2, c2, n);
+        printf("streams shifted by %8ld B: %.3f ms  %.2f TB/s (nt loads + stores)\n", off, t, 3.0 * bytes / t / 1e9);
+    }
     return 0;
 }
