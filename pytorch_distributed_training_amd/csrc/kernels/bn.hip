@@ -21,6 +21,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr long kElemtTableBlocks = 4096;  // bwd_elemt: above this many chunks the coefficient table pays
 constexpr long kSyncPrologueBlocks = 32;  // SyncBN: largest grid whose blocks exchange the sums in their prologue
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 constexpr int kUnrollReduce = 2;  // the backward reduction (two loads, no store per row): 8.0 -> 7.8 ms per step with 2 rows in flight (non-temporal loads)
 constexpr int kUnroll = 4;  // rows per thread and trip in the streaming kernels (bn_apply+res: 1: 5.3, 2: 5.9, 4: 5.8, 8: 5.6 TB/s; 2 vs 4 is a wash end to end)
 
@@ -44,14 +45,19 @@ __device__ __forceinline__ void block_rows(long M, long& r0, long& r1) {
 }
 // The activation streams of these kernels are read once and written once, gigabytes at a time: non-temporal loads and
 // stores (no allocation in the caches on the way) measured 6.25 TB/s against 5.68 TB/s with plain ones on c = a + b
-// (bench/micro/hbm_nt.hip).  -DPDT_BN_PLAIN_LDST builds the plain version.
+// (bench/micro/hbm_nt.hip).  Tensors that fit the caches (the CIFAR-shaped step: 16 MiB and less) are better off with
+// plain accesses (that step: 4.08 vs 4.17 ms), so every kernel exists in both forms (NT) and the launchers pick by
+// size (stream_nt).  -DPDT_BN_PLAIN_LDST builds the plain version only.
+template <bool NT>
 __device__ __forceinline__ bf16x8 ld8(const bf16* p) {
 #ifdef PDT_BN_PLAIN_LDST
     return *reinterpret_cast<const bf16x8*>(p);
 #else
-    return __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+    if constexpr (NT) return __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+    else return *reinterpret_cast<const bf16x8*>(p);
 #endif
 }
+template <bool NT>
 __device__ __forceinline__ void st8(bf16* p, const float (&v)[8]) {
     bf16x8 o;
 #pragma unroll
@@ -59,7 +65,8 @@ __device__ __forceinline__ void st8(bf16* p, const float (&v)[8]) {
 #ifdef PDT_BN_PLAIN_LDST
     *reinterpret_cast<bf16x8*>(p) = o;
 #else
-    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(p));
+    if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<bf16x8*>(p) = o;
 #endif
 }
 __device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
@@ -91,6 +98,7 @@ __device__ __forceinline__ void block_reduce_store(const Map& m, int C, const fl
     }
 }
 
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_bn_stats(const bf16* __restrict__ x, long M, int C,
                                                        float* __restrict__ slab) {
     const Map m = make_map(C);
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_stats(const bf16* __restrict__ 
     block_rows(M, r0, r1);
     float s[8] = {0}, q[8] = {0};
     for (long r = r0 + m.rl; r < r1; r += m.R) {
-        const bf16x8 v = ld8(x + r * C + m.cg * 8);
+        const bf16x8 v = ld8<NT>(x + r * C + m.cg * 8);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float f = (float)v[k];
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restric
 
 // With RELU the kernel also writes one bit per element (uint8 per 8 channels): backward reads this
 // 16x smaller mask instead of re-reading the bf16 output to know where the ReLU was active.
-template <bool RELU, bool RES>
+template <bool NT, bool RELU, bool RES>
 __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ x, const bf16* __restrict__ res,
                                                        bf16* __restrict__ z, uint8_t* __restrict__ mask, long M, int C,
                                                        const float* __restrict__ mean,
@@ -269,8 +277,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ 
         for (int u = 0; u < kUnroll; ++u) {
             const long r = rb + u * S;
             if (r < M) {
-                v[u] = ld8(x + r * C + m.cg * 8);
-                if (RES) rv[u] = ld8(res + r * C + m.cg * 8);
+                v[u] = ld8<NT>(x + r * C + m.cg * 8);
+                if (RES) rv[u] = ld8<NT>(res + r * C + m.cg * 8);
             }
         }
 #pragma unroll
@@ -302,12 +310,12 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const bf16* __restrict__ 
                 }
                 mask[r * m.G + m.cg] = (uint8_t)bits;
             }
-            st8(z + off, o);
+            st8<NT>(z + off, o);
         }
     }
 }
 
-template <bool RELU>
+template <bool NT, bool RELU>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const bf16* __restrict__ dz, const uint8_t* __restrict__ mask,
                                                             const bf16* __restrict__ x, long M, int C,
                                                             const float* __restrict__ mean,
@@ -328,8 +336,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const bf16* __restri
             const long r = rb + u * S;
             bits[u] = 0xffu;
             if (r < M) {
-                g[u] = ld8(dz + r * C + m.cg * 8);
-                xv[u] = ld8(x + r * C + m.cg * 8);
+                g[u] = ld8<NT>(dz + r * C + m.cg * 8);
+                xv[u] = ld8<NT>(x + r * C + m.cg * 8);
                 if (RELU) bits[u] = mask[r * m.G + m.cg];
             }
         }
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_coef(const float* __restric
 }
 
 // dx = k1*dzm + k2*x + k3 with per-channel k's (see host comment); dres = dzm
-template <bool RELU, bool DRES>
+template <bool NT, bool RELU, bool DRES>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restrict__ dz, const uint8_t* __restrict__ mask,
                                                            const bf16* __restrict__ x, bf16* __restrict__ dx,
                                                            bf16* __restrict__ dres, long M, int C,
@@ -500,8 +508,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
             const long r = rb + u * S;
             bits[u] = 0xffu;
             if (r < M) {
-                g[u] = ld8(dz + r * C + m.cg * 8);
-                xv[u] = ld8(x + r * C + m.cg * 8);
+                g[u] = ld8<NT>(dz + r * C + m.cg * 8);
+                xv[u] = ld8<NT>(x + r * C + m.cg * 8);
                 if (RELU) bits[u] = mask[r * m.G + m.cg];
             }
         }
@@ -518,8 +526,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
                 gm[k] = gg;
                 o[k] = k1[k] * gg + k2[k] * (float)xv[u][k] + k3[k];
             }
-            st8(dx + off, o);
-            if (DRES) st8(dres + off, gm);
+            st8<NT>(dx + off, o);
+            if (DRES) st8<NT>(dres + off, gm);
         }
     }
     if (exchange) ipc_end(mb, seq, late);
@@ -528,6 +536,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
 // Two BatchNorms that receive the SAME gradient (the last BN of a bottleneck and the BN of its downsample branch:
 // z = relu(bn3(x) + bn_ds(x_ds))) in one streaming pass: dz and the ReLU mask are read once instead of twice.
 // Both coefficient tables come from k_bn_bwd_coef.
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt2(const bf16* __restrict__ dz, const uint8_t* __restrict__ mask,
                                                             const bf16* __restrict__ xa, const bf16* __restrict__ xb,
                                                             bf16* __restrict__ dxa, bf16* __restrict__ dxb, long M,
@@ -552,9 +561,9 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt2(const bf16* __restri
             const long r = rb + u * S;
             bits[u] = 0xffu;
             if (r < M) {
-                g[u] = ld8(dz + r * C + m.cg * 8);
-                va[u] = ld8(xa + r * C + m.cg * 8);
-                vb[u] = ld8(xb + r * C + m.cg * 8);
+                g[u] = ld8<NT>(dz + r * C + m.cg * 8);
+                va[u] = ld8<NT>(xa + r * C + m.cg * 8);
+                vb[u] = ld8<NT>(xb + r * C + m.cg * 8);
                 if (mask != nullptr) bits[u] = mask[r * m.G + m.cg];
             }
         }
@@ -570,10 +579,22 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt2(const bf16* __restri
                 oa[k] = a1[k] * gg + a2[k] * (float)va[u][k] + a3[k];
                 ob[k] = b1[k] * gg + b2[k] * (float)vb[u][k] + b3[k];
             }
-            st8(dxa + off, oa);
-            st8(dxb + off, ob);
+            st8<NT>(dxa + off, oa);
+            st8<NT>(dxb + off, ob);
         }
     }
+}
+
+// Non-temporal accesses from this tensor size on (bytes of ONE activation tensor of the launch); PDT_STREAM_NT_MIN_MB
+// overrides (0: always, a huge value: never).  Same-box A/B (bench/micro/nt_ab.sh), ms per step at B = 1280 / B = 256 /
+// CIFAR shape under hipGraph: never 84.48 / 20.98 / 4.131, from 512 MiB 83.30, from 128 MiB 82.79 / 20.80, from 32 MiB
+// 82.90 / 20.90 / 4.131, always - / - / 4.178
+bool stream_nt(long bytes) {
+    static const long min_bytes = [] {
+        const char* e = getenv("PDT_STREAM_NT_MIN_MB");
+        return (e ? atol(e) : 128L) << 20;
+    }();
+    return bytes >= min_bytes;
 }
 
 // Grid of the streaming kernels: ONE chunk (kUnroll * R adjacent rows, 16 KiB per tensor) per block, blocks
@@ -616,6 +637,7 @@ __device__ __forceinline__ void bn_coeffs(const Map& m, const float* mean, const
     }
 }
 
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_bn_relu_maxpool_fwd(const bf16* __restrict__ u, bf16* __restrict__ y,
                                                                  uint8_t* __restrict__ argmax,
                                                                  uint8_t* __restrict__ mask, PoolGeom g,
@@ -652,7 +674,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_maxpool_fwd(const bf16* __
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const int wi = min(max(wo * 2 - 1 + s, 0), g.W - 1);
-            v9[r * 3 + s] = ld8(u + (uint32_t)((((int)bb * g.H + hi) * g.W + wi) * g.C + m.cg * 8));
+            v9[r * 3 + s] = ld8<NT>(u + (uint32_t)((((int)bb * g.H + hi) * g.W + wi) * g.C + m.cg * 8));
         }
     }
     // The kernel is VALU-bound (a first version: 1500 vector instructions per thread = the whole run time), so value
@@ -695,8 +717,13 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_maxpool_fwd(const bf16* __
         plo |= (8u - (key[k] & 0xfu)) << (8 * k);
         phi |= (8u - (key[4 + k] & 0xfu)) << (8 * k);
     }
-    *reinterpret_cast<uint4*>(y + off) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-    *reinterpret_cast<uint2*>(argmax + off) = make_uint2(plo, phi);
+    if constexpr (NT) {
+        st_stream(y + off, u32x4{ow[0], ow[1], ow[2], ow[3]});
+        __builtin_nontemporal_store(u32x2_t{plo, phi}, reinterpret_cast<u32x2_t*>(argmax + off));
+    } else {
+        *reinterpret_cast<uint4*>(y + off) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        *reinterpret_cast<uint2*>(argmax + off) = make_uint2(plo, phi);
+    }
 }
 
 int grid_for(long M, int C) {
@@ -713,7 +740,8 @@ int bn_parts(long M, int C) { return grid_for(M, C); }
 
 void launch_bn_stats(const void* x, long M, int C, float* slab, int parts, hipStream_t s) {
     const size_t lds = (size_t)kThreads * 16 * sizeof(float);
-    hipLaunchKernelGGL(k_bn_stats, dim3(parts), dim3(kThreads), lds, s, (const bf16*)x, M, C, slab);
+    if (stream_nt(M * C * 2)) hipLaunchKernelGGL(k_bn_stats<true>, dim3(parts), dim3(kThreads), lds, s, (const bf16*)x, M, C, slab);
+    else hipLaunchKernelGGL(k_bn_stats<false>, dim3(parts), dim3(kThreads), lds, s, (const bf16*)x, M, C, slab);
 }
 
 static IpcMailboxes no_exchange() {
@@ -737,25 +765,35 @@ void launch_bn_apply(const void* x, const void* residual, void* z, uint8_t* mask
     const int R = kThreads / (C >> 3);
     const long blocks = stream_blocks(M, R, 0);
     dim3 grid((int)blocks), block(kThreads);
-#define PDT_APPLY(RELU, RES)                                                                                    \
-    hipLaunchKernelGGL((k_bn_apply<RELU, RES>), grid, block, 0, s, (const bf16*)x, (const bf16*)residual, (bf16*)z, \
+    const bool nt = stream_nt(M * C * 2);
+#define PDT_APPLY1(NT, RELU, RES)                                                                                    \
+    hipLaunchKernelGGL((k_bn_apply<NT, RELU, RES>), grid, block, 0, s, (const bf16*)x, (const bf16*)residual, (bf16*)z, \
                        mask, M, C, mean, invstd, gamma, beta, res_affine)
+#define PDT_APPLY(RELU, RES)              \
+    do {                                  \
+        if (nt) PDT_APPLY1(true, RELU, RES);  \
+        else PDT_APPLY1(false, RELU, RES);    \
+    } while (0)
     if (relu && residual) PDT_APPLY(true, true);
     else if (relu) PDT_APPLY(true, false);
     else if (residual) PDT_APPLY(false, true);
     else PDT_APPLY(false, false);
 #undef PDT_APPLY
+#undef PDT_APPLY1
 }
 
 void launch_bn_bwd_reduce(const void* dz, const void* z, const void* x, long M, int C, const float* mean,
                           const float* invstd, int relu, float* slab, int parts, hipStream_t s) {
     const size_t lds = (size_t)kThreads * 16 * sizeof(float);
-    if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_reduce<true>), dim3(parts), dim3(kThreads), lds, s, (const bf16*)dz,
-                           (const uint8_t*)z, (const bf16*)x, M, C, mean, invstd, slab);
-    else
-        hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(parts), dim3(kThreads), lds, s, (const bf16*)dz,
-                           (const uint8_t*)z, (const bf16*)x, M, C, mean, invstd, slab);
+    const bool nt = stream_nt(M * C * 2);
+#define PDT_REDUCE(NT, RELU)                                                                                       \
+    hipLaunchKernelGGL((k_bn_bwd_reduce<NT, RELU>), dim3(parts), dim3(kThreads), lds, s, (const bf16*)dz,           \
+                       (const uint8_t*)z, (const bf16*)x, M, C, mean, invstd, slab)
+    if (relu && nt) PDT_REDUCE(true, true);
+    else if (relu) PDT_REDUCE(false, true);
+    else if (nt) PDT_REDUCE(true, false);
+    else PDT_REDUCE(false, false);
+#undef PDT_REDUCE
 }
 
 void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx, void* dres, long M, int C,
@@ -779,15 +817,22 @@ void launch_bn_bwd_elemt(const void* dz, const void* z, const void* x, void* dx,
         coef = nullptr;
     const long blocks = stream_blocks(M, R, table ? 0 : 2048);
     dim3 grid((int)blocks), block(kThreads);
-#define PDT_ELEMT(RELU, DRES)                                                                                  \
-    hipLaunchKernelGGL((k_bn_bwd_elemt<RELU, DRES>), grid, block, 0, s, (const bf16*)dz, (const uint8_t*)z,       \
+    const bool nt = stream_nt(M * C * 2);
+#define PDT_ELEMT1(NT, RELU, DRES)                                                                                  \
+    hipLaunchKernelGGL((k_bn_bwd_elemt<NT, RELU, DRES>), grid, block, 0, s, (const bf16*)dz, (const uint8_t*)z,       \
                        (const bf16*)x, (bf16*)dx, (bf16*)dres, M, C, mean, invstd, gamma, psums, nps, sums_out, count,   \
                        count_dev, coef, mb)
+#define PDT_ELEMT(RELU, DRES)                  \
+    do {                                       \
+        if (nt) PDT_ELEMT1(true, RELU, DRES);  \
+        else PDT_ELEMT1(false, RELU, DRES);    \
+    } while (0)
     if (relu && dres) PDT_ELEMT(true, true);
     else if (relu) PDT_ELEMT(true, false);
     else if (dres) PDT_ELEMT(false, true);
     else PDT_ELEMT(false, false);
 #undef PDT_ELEMT
+#undef PDT_ELEMT1
 }
 
 void launch_bn_bwd_elemt2(const void* dz, const void* mask, long M, int C, float count, const float* count_dev,
@@ -800,9 +845,13 @@ void launch_bn_bwd_elemt2(const void* dz, const void* mask, long M, int C, float
                            p->invstd, p->gamma, count, count_dev, p->sums_out, p->coef, mb);
     const int U = kUnroll / 2 > 0 ? kUnroll / 2 : 1;
     const long blocks = (M + (long)R * U - 1) / ((long)R * U);
-    hipLaunchKernelGGL(k_bn_bwd_elemt2, dim3((unsigned)blocks), dim3(kThreads), 0, s, (const bf16*)dz,
-                       (const uint8_t*)mask, (const bf16*)a.x, (const bf16*)b.x, (bf16*)a.dx, (bf16*)b.dx, M, C,
-                       (const float*)a.coef, (const float*)b.coef);
+#define PDT_ELEMT2(NT)                                                                                            \
+    hipLaunchKernelGGL(k_bn_bwd_elemt2<NT>, dim3((unsigned)blocks), dim3(kThreads), 0, s, (const bf16*)dz,            \
+                       (const uint8_t*)mask, (const bf16*)a.x, (const bf16*)b.x, (bf16*)a.dx, (bf16*)b.dx, M, C,     \
+                       (const float*)a.coef, (const float*)b.coef)
+    if (stream_nt(M * C * 2)) PDT_ELEMT2(true);
+    else PDT_ELEMT2(false);
+#undef PDT_ELEMT2
 }
 
 namespace {
@@ -828,8 +877,12 @@ void launch_bn_relu_maxpool_fwd(const void* u, void* y, uint8_t* argmax, uint8_t
     check_pool_index_space((long)B * H * W, C);
     const int R = kThreads / (C >> 3);
     const long P = (long)B * Ho * Wo;
-    hipLaunchKernelGGL(k_bn_relu_maxpool_fwd, dim3((unsigned)((P + R - 1) / R)), dim3(kThreads), 0, s, (const bf16*)u,
-                       (bf16*)y, argmax, mask, pool_geom(B, H, W, C, Ho, Wo, false), mean, invstd, gamma, beta);
+#define PDT_POOLF(NT)                                                                                                 \
+    hipLaunchKernelGGL(k_bn_relu_maxpool_fwd<NT>, dim3((unsigned)((P + R - 1) / R)), dim3(kThreads), 0, s, (const bf16*)u, \
+                       (bf16*)y, argmax, mask, pool_geom(B, H, W, C, Ho, Wo, false), mean, invstd, gamma, beta)
+    if (stream_nt((long)B * H * W * C * 2)) PDT_POOLF(true);
+    else PDT_POOLF(false);
+#undef PDT_POOLF
 }
 
 }  // namespace pdt

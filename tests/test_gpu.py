@@ -736,9 +736,11 @@ def test_bf16_gradient_buckets_follow_the_fp32_run():
         dt = {t.dtype for t in eng.net.reducer.bucket_tensors()}
         assert dt == ({torch.bfloat16} if gd == "bf16" else {torch.float32})
         assert all(p.grad.dtype == torch.float32 for p in eng.net.parameters())
-    # (two training runs that differ in the rounding of every gradient: the trajectories separate slowly; the loss falls 30x meanwhile)
-    assert runs["bf16"] == pytest.approx(runs["fp32"], rel=0.1, abs=0.03), runs
-    assert runs["bf16"][-1] < 0.5 * runs["bf16"][0]
+    # (two training runs that differ in the rounding of every gradient: identical first loss, then the trajectories
+    # separate while the loss falls 30x on the one batch; the later steps are only required to stay in the same range)
+    assert runs["bf16"][:2] == pytest.approx(runs["fp32"][:2], rel=0.02), runs
+    assert runs["bf16"] == pytest.approx(runs["fp32"], rel=0.25, abs=0.05), runs
+    assert runs["bf16"][-1] < 0.5 * runs["bf16"][0] and runs["fp32"][-1] < 0.5 * runs["fp32"][0]
 
 
 @pytest.mark.parametrize("opt", ["sgd", "adam"])
