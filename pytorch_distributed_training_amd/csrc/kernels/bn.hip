@@ -16,6 +16,7 @@
 #include "../comm/ipc_device.h"
 
 namespace pdt {
+bool stream_nt(long bytes);
 namespace {
 
 constexpr int kThreads = 256;
@@ -585,18 +586,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt2(const bf16* __restri
     }
 }
 
-// Non-temporal accesses from this tensor size on (bytes of ONE activation tensor of the launch); PDT_STREAM_NT_MIN_MB
-// overrides (0: always, a huge value: never).  Same-box A/B (bench/micro/nt_ab.sh), ms per step at B = 1280 / B = 256 /
-// CIFAR shape under hipGraph: never 84.48 / 20.98 / 4.131, from 512 MiB 83.30, from 128 MiB 82.79 / 20.80, from 32 MiB
-// 82.90 / 20.90 / 4.131, always - / - / 4.178
-bool stream_nt(long bytes) {
-    static const long min_bytes = [] {
-        const char* e = getenv("PDT_STREAM_NT_MIN_MB");
-        return (e ? atol(e) : 128L) << 20;
-    }();
-    return bytes >= min_bytes;
-}
-
 // Grid of the streaming kernels: ONE chunk (kUnroll * R adjacent rows, 16 KiB per tensor) per block, blocks
 // dispatched in order -> the chip walks each tensor front to back like a plain vectorised elementwise
 // kernel does (5.8 TB/s; a 2048-block grid-stride loop over the same rows reached 5.1, hbm_ceiling.py).
@@ -735,6 +724,19 @@ int grid_for(long M, int C) {
 }
 
 }  // namespace
+
+// Non-temporal accesses from this tensor size on (bytes of ONE activation tensor of the launch); PDT_STREAM_NT_MIN_MB
+// overrides (0: always, a huge value: never).  Same-box A/B (bench/micro/nt_ab.sh), ms per step at B = 1280 / B = 256 /
+// CIFAR shape under hipGraph: never 84.48 / 20.98 / 4.131, from 512 MiB 83.30, from 128 MiB 82.79 / 20.80, from 32 MiB
+// 82.90 / 20.90 / 4.131, always - / - / 4.178
+bool stream_nt(long bytes) {
+    static const long min_bytes = [] {
+        const char* e = getenv("PDT_STREAM_NT_MIN_MB");
+        return (e ? atol(e) : 128L) << 20;
+    }();
+    return bytes >= min_bytes;
+}
+
 
 int bn_parts(long M, int C) { return grid_for(M, C); }
 

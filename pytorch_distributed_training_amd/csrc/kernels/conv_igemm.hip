@@ -455,7 +455,8 @@ __global__ __launch_bounds__(256, MINW) void k_conv_igemm(const bf16* __restrict
                     r1[k] += gg * ((float)xv[k] - mu[k]) * is[k];
                 }
             }
-            st_stream(y + pix * g.N + ncol, __builtin_bit_cast(u32x4, v));
+            if (g.stream_out) st_stream(y + pix * g.N + ncol, __builtin_bit_cast(u32x4, v));
+            else *reinterpret_cast<bf16x8*>(y + pix * g.N + ncol) = v;
         }
     }
     if (bnr) {
@@ -526,6 +527,7 @@ void launch_cfg(const void* x, const void* w, void* y, const ConvGeom& g, float*
     gd.div_noh = make_fastdiv((uint32_t)g.nOH);
     gd.div_wout = make_fastdiv((uint32_t)g.Wout);
     gd.div_hout = make_fastdiv((uint32_t)g.Hout);
+    gd.stream_out = stream_nt((long)g.B * g.Hout * g.Wout * g.N * 2) ? 1 : 0;
     if (M >= (1L << 31)) {
         fprintf(stderr, "conv_igemm: %ld output pixels exceed the 31-bit index space\n", M);
         abort();

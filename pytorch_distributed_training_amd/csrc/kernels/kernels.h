@@ -170,6 +170,8 @@ struct ConvGeom {
     // Wout, Hout.  64-bit '/' and '%' by runtime values cost ~40 vector instructions each; a short-K launch did
     // eight of them per thread in its prologue and up to 32 in its epilogue.
     FastDiv div_now, div_noh, div_wout, div_hout;
+    // (set by launch_conv_igemm) the output tensor is large: store it with the non-temporal hint (see common.h)
+    int stream_out;
     // elements per input pixel in memory; 0 = C (dense NHWC).  The packed stem runs with C = 32 (one filter
     // row: 8 kw slots x 4 channels, contiguous in memory) over pixels of 4 elements.
     int pix_elems;
@@ -188,6 +190,7 @@ struct ConvGeom {
 // cfg: 0 = tuned heuristic; 6 / 8 / 11 / 12 = 128-row tile builds (4-stage ring / 3-stage ring / 2-stage 128-register /
 // 3-stage 128-register), 10 = 256x128 tile, 15 = 256x64 tile, 5 / 9 = register-staged builds (see conv_igemm.hip)
 int conv_igemm_m_tiles(const ConvGeom& g, int* bm_out, int cfg = 0);
+bool stream_nt(long bytes);  // bn.hip: non-temporal accesses from this tensor size on
 void launch_conv_igemm(const void* x, const void* w, void* y, const ConvGeom& g, float* stats_slab,
                        hipStream_t s, int cfg = 0);
 
