@@ -64,6 +64,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void k_stem_win(const StemWinArgs a)
     const uint32_t lds0 = lds_address(smem);
     const uint32_t buf_bytes = (uint32_t)a.ppw * 8192u;
     const int fpr = a.Wo >> 4;  // fragments per output row == fragments per wave
+    char* xchg = smem + 2 * (size_t)buf_bytes + wave * 2304;  // this wave's output exchange tile [16][144 B]
     const uint32_t row_bytes = (uint32_t)a.Wp * 8u;
 
     auto issue = [&](int tile, int buf) {
@@ -121,11 +122,23 @@ __global__ __launch_bounds__(SW_THREADS, 1) void k_stem_win(const StemWinArgs a)
                         s[k] += v;
                         q[k] += v * v;
                     }
-                bf16* dst = reinterpret_cast<bf16*>(a.y) + ((size_t)(b * a.Ho + oh) * a.Wo + fc * 16 + px) * 64 + 16 * g;
-                // (plain stores: a lane writes 32 B of a 128-B pixel and the L2 merges the four lane groups into full
-                // lines; with the non-temporal hint the kernel took 1.5x as long)
-                *reinterpret_cast<bf16x8*>(dst) = o[0];
-                *reinterpret_cast<bf16x8*>(dst + 8) = o[1];
+                // A lane holds 32 B of a 128-B pixel, so a store instruction straight from here covers every line in
+                // pieces: fine for plain stores (the L2 merges them) but 1.5x slower with the non-temporal hint, and
+                // plain stores of 2 GB leave dirty lines that the next kernel's reads wait behind.  The fragment
+                // (16 pixels x 128 B) therefore takes a turn through this wave's 2.25 KiB of LDS (pixel pitch 144 B:
+                // conflict-free both ways) and leaves as two linear 1-KiB non-temporal stores.
+                char* xs = xchg + px * 144 + g * 32;
+                *reinterpret_cast<bf16x8*>(xs) = o[0];
+                *reinterpret_cast<bf16x8*>(xs + 16) = o[1];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const u32x4 w0 = *reinterpret_cast<const u32x4*>(xchg + (lane >> 3) * 144 + (lane & 7) * 16);
+                const u32x4 w1 = *reinterpret_cast<const u32x4*>(xchg + (8 + (lane >> 3)) * 144 + (lane & 7) * 16);
+                char* dst = reinterpret_cast<char*>(a.y) + ((size_t)(b * a.Ho + oh) * a.Wo + fc * 16) * 128 + lane * 16;
+                st_stream(dst, w0);
+                st_stream(dst + 1024, w1);
+                __builtin_amdgcn_wave_barrier();  // (the next fragment's writes come after these reads)
             } else {
                 full = false;
             }
@@ -322,7 +335,7 @@ void set_stem_win_mode(int mode) { g_stem_win_force = mode; }
 bool conv_stem_win_ok(int B, int Ho, int Wo, int N) {
     const int mode = g_stem_win_force >= 0 ? g_stem_win_force : stem_win_mode();
     if (mode == 0 || N != 64 || Wo < 16 || Wo % 16 != 0 || Ho < 1) return false;
-    if (2L * stem_ppw(Wo) * 8192 > 160 * 1024) return false;
+    if (2L * stem_ppw(Wo) * 8192 + 8 * 2304 > 160 * 1024) return false;
     const long tiles = (long)B * ((Ho + RT - 1) / RT);
     if (tiles >= (1L << 31)) return false;
     // a persistent grid of one workgroup per CU: below two tiles per CU the implicit-GEMM launch fills the chip better
@@ -343,7 +356,7 @@ int conv_stem_win_grid(int B, int Ho) {
 
 void launch_conv_stem_win(const void* xp, const void* wp, void* y, float* slab, int B, int Ho, int Wo, hipStream_t s) {
     const long xp_bytes = (long)B * (2 * Ho + 6) * (2 * Wo + 8) * 8;
-    if (Wo < 16 || Wo % 16 != 0 || 2L * stem_ppw(Wo) * 8192 > 160 * 1024 || xp_bytes >= (1L << 31) ||
+    if (Wo < 16 || Wo % 16 != 0 || 2L * stem_ppw(Wo) * 8192 + 8 * 2304 > 160 * 1024 || xp_bytes >= (1L << 31) ||
         (long)B * Ho * Wo * 128 >= (1L << 32)) {
         fprintf(stderr, "launch_conv_stem_win: unsupported geometry %d x %d x %d\n", B, Ho, Wo);
         abort();
@@ -355,7 +368,7 @@ void launch_conv_stem_win(const void* xp, const void* wp, void* y, float* slab, 
     a.tiles = B * a.row_tiles;
     a.ppw = stem_ppw(Wo);
     a.xp_bytes = (uint32_t)xp_bytes;
-    const int lds = 2 * a.ppw * 8192;
+    const int lds = 2 * a.ppw * 8192 + 8 * 2304;
     static int attr_lds = 0;
     if (lds > attr_lds) {
         PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_win),
