@@ -55,6 +55,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int krow0, int colba
 struct WgradArgs {
     int B, Hin, Win, C, Hout, Wout, N, KH, KW, stride, pad;
     int n_tiles, c_tiles, splits, xcd_remap;
+    int dy_stream, x_stream;  // the operand is read by one tile column / row only: non-temporal loads
     long M, m_per_split;
     FastDiv div_wo, div_howo;
     uint32_t x_bytes, dy_bytes;
@@ -152,12 +153,12 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const bf16* __restrict__ 
         const __amdgpu_buffer_rsrc_t rdy = make_rsrc(reinterpret_cast<const char*>(dy) + mbase * a.N * 2,
                                                      left > 0 ? (uint32_t)(left * a.N * 2) : 0u);
 #pragma unroll
-        for (int p = 0; p < PN; ++p) rn[p] = buffer_load_bf16x8(rdy, vn[p]);
+        for (int p = 0; p < PN; ++p) rn[p] = a.dy_stream ? buffer_load_bf16x8_stream(rdy, vn[p]) : buffer_load_bf16x8(rdy, vn[p]);
 #pragma unroll
         for (int p = 0; p < PC; ++p) {
             const int hi = __mul24(xho[p], a.stride) + dr, wi = __mul24(xwo[p], a.stride) + ds;
             const bool ok = c_ok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
-            rc[p] = buffer_load_bf16x8(rx, ok ? xoff[p] : kOOB);
+            rc[p] = a.x_stream ? buffer_load_bf16x8_stream(rx, ok ? xoff[p] : kOOB) : buffer_load_bf16x8(rx, ok ? xoff[p] : kOOB);
             // advance this row by KM pixels
             int wo = xwo[p] + a.kw;
             const bool cw = wo >= a.Wout;
@@ -241,6 +242,15 @@ void launch_cfg(const void* dy, const void* x, float* slab, const WgradGeom& g, 
     a.n_tiles = (g.N + TNW - 1) / TNW;
     a.c_tiles = (g.C + TCW - 1) / TCW;
     a.splits = g.splits;
+    // A pointwise layer between a narrow and a wide tensor reads the WIDE one through a single tile column / row:
+    // exactly once, whole 128-B lines per row -> non-temporal (PDT_WGRAD_STREAM=0: off)
+    static const bool stream_on = [] {
+        const char* e = std::getenv("PDT_WGRAD_STREAM");
+        return !(e && e[0] == '0');
+    }();
+    const bool one_tap = g.KH * g.KW == 1;
+    a.dy_stream = stream_on && one_tap && a.c_tiles == 1 ? 1 : 0;
+    a.x_stream = stream_on && one_tap && a.n_tiles == 1 && g.stride == 1 ? 1 : 0;
     // measured on MI355X (bench/resnet50_roofline.py, B=256): sharing one XCD's L2 between the taps / tiles of a
     // split wins where the layer is fetch-bound (64-128 channel 3x3: 260 -> 187 us, every 1x1: -5..-15 %) and
     // loses where >= 36 MFMA-bound workgroups then hammer the same L2 lines at once (256-channel 3x3: 100 -> 123 us)

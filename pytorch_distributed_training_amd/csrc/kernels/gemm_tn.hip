@@ -67,6 +67,7 @@ struct TnArgs {
     int kh, kw;  // 32 pixels = kb images + kh rows + kw columns of the output grid
     uint32_t xstep, xwrap_w, xwrap_h, x_bytes;
     int xcd_remap;
+    int dy_stream, x_stream;  // pointwise layer, operand read by ONE tile column / row: non-temporal DMA
 };
 
 // fragment of MFMA 16x16x32 from a row-major [k][col] tile: lane l gets (col = colbase + l % 16, k = 8 * (l / 16) + 0..7)
@@ -159,14 +160,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn(const TnArgs a) {
         const uint32_t dst = piece_base + (uint32_t)((tt % TSTAGES) * TSTAGE_BYTES);
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(tt * TKM * a.N * 2);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) lds_dma16s(rdy, vdy[j], soff, dst + (uint32_t)(j * 1024));
+        for (int j = 0; j < 2; ++j) {
+            if (a.dy_stream) lds_dma16s_stream(rdy, vdy[j], soff, dst + (uint32_t)(j * 1024));
+            else lds_dma16s(rdy, vdy[j], soff, dst + (uint32_t)(j * 1024));
+        }
     };
     auto issue_x = [&](int tt) {
         const uint32_t dst = piece_base + (uint32_t)((tt % TSTAGES) * TSTAGE_BYTES + OPER_BYTES);
         if (LINEAR) {
             const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(tt * TKM * a.C * 2);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) lds_dma16s(rx, vx[j], soff, dst + (uint32_t)(j * 1024));
+            for (int j = 0; j < 2; ++j) {
+                if (a.x_stream) lds_dma16s_stream(rx, vx[j], soff, dst + (uint32_t)(j * 1024));
+                else lds_dma16s(rx, vx[j], soff, dst + (uint32_t)(j * 1024));
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -306,11 +313,17 @@ void launch_gemm_tn(const void* dy, const void* x, float* slab, const WgradGeom&
         return e ? std::atoi(e) : 1;
     }();
     // pointwise layers with many tiles: 16+ workgroups on the same rows of one L2 measured 3 % slower than spread out
-    a.xcd_remap = remap && (g.KH * g.KW > 1 || a.n_tiles * a.c_tiles <= 8 || !linear_layer(g));
+    a.xcd_remap = remap >= 2 || (remap && (g.KH * g.KW > 1 || (g.N / 256) * (g.C / 256) <= 8 || !linear_layer(g)));  // (2: always)
     a.M = (long)g.B * g.Hout * g.Wout;
     a.N = g.N; a.C = g.C; a.T = g.KH * g.KW; a.KW = g.KW;
     a.Hin = g.Hin; a.Win = g.Win; a.Hout = g.Hout; a.Wout = g.Wout; a.stride = g.stride; a.pad = g.pad;
     a.n_tiles = g.N / 256; a.c_tiles = g.C / 256; a.splits = g.splits;
+    static const bool stream_on = [] {
+        const char* e = std::getenv("PDT_WGRAD_STREAM");
+        return !(e && e[0] == '0');
+    }();
+    a.dy_stream = stream_on && linear_layer(g) && a.c_tiles == 1 ? 1 : 0;
+    a.x_stream = stream_on && linear_layer(g) && a.n_tiles == 1 ? 1 : 0;
     long per = (a.M + g.splits - 1) / g.splits;
     per = (per + TKM - 1) / TKM * TKM;
     a.m_per_split = per;
