@@ -312,8 +312,10 @@ void launch_gemm_tn(const void* dy, const void* x, float* slab, const WgradGeom&
         const char* e = std::getenv("PDT_WGRAD_TN_REMAP");
         return e ? std::atoi(e) : 1;
     }();
-    // pointwise layers with many tiles: 16+ workgroups on the same rows of one L2 measured 3 % slower than spread out
-    a.xcd_remap = remap >= 2 || (remap && (g.KH * g.KW > 1 || (g.N / 256) * (g.C / 256) <= 8 || !linear_layer(g)));  // (2: always)
+    // (Same-box A/B on the final tree: grouping also the pointwise layers with many tiles is +0.8 % on ViT-B/16 and
+    // neutral on ResNet-50; an earlier "3 % slower" reading came from a launcher that used the tile counts before
+    // setting them.)
+    a.xcd_remap = remap ? 1 : 0;
     a.M = (long)g.B * g.Hout * g.Wout;
     a.N = g.N; a.C = g.C; a.T = g.KH * g.KW; a.KW = g.KW;
     a.Hin = g.Hin; a.Win = g.Win; a.Hout = g.Hout; a.Wout = g.Wout; a.stride = g.stride; a.pad = g.pad;
