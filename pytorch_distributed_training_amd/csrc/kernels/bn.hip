@@ -24,6 +24,7 @@ constexpr long kElemtTableBlocks = 4096;  // bwd_elemt: above this many chunks t
 constexpr long kSyncPrologueBlocks = 32;  // SyncBN: largest grid whose blocks exchange the sums in their prologue
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 constexpr int kUnrollReduce = 2;  // the backward reduction (two loads, no store per row): 8.0 -> 7.8 ms per step with 2 rows in flight (non-temporal loads)
+constexpr int kUnroll2 = 4;  // k_bn_bwd_elemt2
 constexpr int kUnroll = 4;  // rows per thread and trip in the streaming kernels (bn_apply+res: 1: 5.3, 2: 5.9, 4: 5.8, 8: 5.6 TB/s; 2 vs 4 is a wash end to end)
 
 struct Map {
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt2(const bf16* __restri
     ld8f(coef_b + m.cg * 8, b1);
     ld8f(coef_b + C + m.cg * 8, b2);
     ld8f(coef_b + 2 * C + m.cg * 8, b3);
-    constexpr int U = kUnroll / 2 > 0 ? kUnroll / 2 : 1;  // three input streams: half the rows in flight per trip
+    constexpr int U = kUnroll2;  // rows in flight per trip (three input streams)
     const long S = m.R;
     const long T = (long)gridDim.x * U * m.R;
     for (long rb = (long)blockIdx.x * U * m.R + m.rl; rb < M; rb += T) {
@@ -845,7 +846,7 @@ void launch_bn_bwd_elemt2(const void* dz, const void* mask, long M, int C, float
     for (const BnBwdSide* p : sides)  // SyncBatchNorm: one exchange per table, in the same order on every rank
         hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 31) / 32), dim3(kThreads), 0, s, p->psums, p->nps, C, p->mean,
                            p->invstd, p->gamma, count, count_dev, p->sums_out, p->coef, mb);
-    const int U = kUnroll / 2 > 0 ? kUnroll / 2 : 1;
+    const int U = kUnroll2;
     const long blocks = (M + (long)R * U - 1) / ((long)R * U);
 #define PDT_ELEMT2(NT)                                                                                            \
     hipLaunchKernelGGL(k_bn_bwd_elemt2<NT>, dim3((unsigned)blocks), dim3(kThreads), 0, s, (const bf16*)dz,            \
