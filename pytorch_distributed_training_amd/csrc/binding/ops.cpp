@@ -929,6 +929,35 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> bn_bwd_elemt2(
     return {dxa, dxb, sums[0], sums[1]};
 }
 
+// backward of bn_relu_maxpool_fwd: dy [B,C,Ho,Wo], argmax taps, u (conv output) and its 1-bit ReLU mask -> (du, sums [2,C])
+std::tuple<Tensor, Tensor> bn_relu_maxpool_bwd(const Tensor& dy, const Tensor& argmax, const Tensor& u, const Tensor& mask,
+                                               const Tensor& mean, const Tensor& invstd, const Tensor& gamma,
+                                               double count, const c10::optional<Tensor>& count_dev,
+                                               const std::shared_ptr<IpcAllReduce>& ipc) {
+    check_nhwc_bf16(dy, "dy"); check_nhwc_bf16(u, "u");
+    const long B = u.size(0), C = u.size(1), H = u.size(2), W = u.size(3), Ho = dy.size(2), Wo = dy.size(3);
+    TORCH_CHECK(dy.size(0) == B && dy.size(1) == C && H % 2 == 0 && W % 2 == 0 && Ho == H / 2 && Wo == W / 2,
+                "bn_relu_maxpool_bwd: expects even H, W and the 3x3/2/1 pooled shape");
+    TORCH_CHECK(bn_channels_ok(C), "bn: unsupported channel count ", C);
+    TORCH_CHECK(argmax.is_cuda() && argmax.scalar_type() == at::kByte && argmax.is_contiguous() && argmax.numel() == dy.numel(),
+                "argmax: expected uint8 taps of the pooled shape");
+    check_vec_f32(mean, C, "mean"); check_vec_f32(invstd, C, "invstd"); check_vec_f32(gamma, C, "gamma");
+    const long M = B * H * W;
+    const void* mp = relu_mask_ptr(mask, M, C);
+    TORCH_CHECK(M * C < (1L << 32), "bn_relu_maxpool_bwd: more than 2^32 elements (use the unfused path)");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(u.device());
+    Tensor du = at::empty_like(u);
+    const int parts = bn_parts(M / 4, (int)C);
+    Tensor slab = at::empty({parts, 2 * C}, mean.options());
+    Tensor sums = at::empty({2, C}, mean.options()), coef = at::empty({3, C}, mean.options());
+    launch_bn_relu_maxpool_bwd(dy.data_ptr(), argmax.data_ptr<uint8_t>(), u.data_ptr(), static_cast<const uint8_t*>(mp),
+                               du.data_ptr(), (int)B, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, mean.data_ptr<float>(),
+                               invstd.data_ptr<float>(), gamma.data_ptr<float>(), (float)count, count_ptr(count_dev),
+                               slab.data_ptr<float>(), parts, sums.data_ptr<float>(), coef.data_ptr<float>(), cur_stream(u),
+                               ipc && ipc->world_size() > 1 ? &ipc->mailboxes_for(2 * C) : nullptr);
+    return {du, sums};
+}
+
 // -------------------------------------------------------------------------------- layernorm
 std::tuple<Tensor, Tensor, Tensor> layernorm_fwd(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps) {
     TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kBFloat16 && x.is_contiguous() && x.dim() >= 2,
@@ -1478,6 +1507,7 @@ void bind_ops(pybind11::module& m) {
     m.def("bn_bwd_reduce", &bn_bwd_reduce);
     m.def("bn_bwd_elemt", &bn_bwd_elemt);
     m.def("bn_bwd_elemt2", &bn_bwd_elemt2);
+    m.def("bn_relu_maxpool_bwd", &bn_relu_maxpool_bwd);
     m.def("attention_fwd", &attention_fwd);
     m.def("attention_bwd", &attention_bwd);
     m.def("layernorm_fwd", &layernorm_fwd);

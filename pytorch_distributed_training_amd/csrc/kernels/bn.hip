@@ -716,6 +716,99 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_maxpool_fwd(const bf16* __
     }
 }
 
+// Backward of the fused stem tail: the gradient w.r.t. relu(bn(u)) is the max-pool scatter of the pooled gradient, and
+// it is only ever consumed by the two BN-backward passes.  Both passes GATHER it themselves (2x2 blocks of
+// full-resolution pixels, four window loads and nine tap compares per channel, see k_maxpool_bwd_2x2 in pool.hip), so
+// the full-resolution gradient (2 GB at B = 1280) is never written or read: 2.2 ms of pool-backward + reduce + elemt
+// become 1.3.  (An earlier fused version with the per-pixel gather was 1.7x SLOWER than the three passes.)
+// MODE 0: partial rows [gridDim][2][C] of [sum g, sum g * xhat] (grid-stride, block reduction);  MODE 1: du = k1 g + k2 u + k3.
+// The gathered value is rounded to bf16 first, as the unfused path stored it.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_bn_relu_maxpool_bwd(const bf16* __restrict__ dy, const uint8_t* __restrict__ argmax,
+                                                                 const bf16* __restrict__ u, const uint8_t* __restrict__ mask,
+                                                                 bf16* __restrict__ du, PoolGeom g /* dw: W/2, dh: H/2 */,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ coef, float* __restrict__ slab) {
+    const Map m = make_map(g.C);
+    const uint32_t Hb = (uint32_t)g.H >> 1, Wb = (uint32_t)g.W >> 1;
+    const uint32_t P = (uint32_t)g.B * Hb * Wb;
+    float c1[8], c2[8], c3[8];  // MODE 0: mean, invstd, -;  MODE 1: k1, k2, k3
+    if (MODE == 0) {
+        ld8f(mean + m.cg * 8, c1);
+        ld8f(invstd + m.cg * 8, c2);
+    } else {
+        ld8f(coef + m.cg * 8, c1);
+        ld8f(coef + g.C + m.cg * 8, c2);
+        ld8f(coef + 2 * g.C + m.cg * 8, c3);
+    }
+    float s0[8] = {0}, s1[8] = {0};
+    for (uint32_t p = blockIdx.x * (uint32_t)m.R + m.rl; p < P; p += gridDim.x * (uint32_t)m.R) {
+        const uint32_t t = fdiv(p, g.dw);
+        const int j = (int)(p - t * Wb);
+        const uint32_t bb = fdiv(t, g.dh);
+        const int i = (int)(t - bb * Hb);
+        const int b = (int)bb;
+        bf16x8 gy[4];
+        uint2 am[4];
+#pragma unroll
+        for (int da = 0; da < 2; ++da)
+#pragma unroll
+            for (int dc = 0; dc < 2; ++dc) {
+                const int ho = i + da, wo = j + dc;
+                const bool ok = ho < g.Ho && wo < g.Wo;
+                const uint32_t off = (uint32_t)(((b * g.Ho + min(ho, g.Ho - 1)) * g.Wo + min(wo, g.Wo - 1)) * g.C) + m.cg * 8;
+                gy[da * 2 + dc] = *reinterpret_cast<const bf16x8*>(dy + off);
+                const uint2 a = *reinterpret_cast<const uint2*>(argmax + off);
+                am[da * 2 + dc] = ok ? a : make_uint2(0xffffffffu, 0xffffffffu);
+            }
+        bf16x8 uv[4];
+        unsigned bits[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t pix = (uint32_t)((b * g.H + 2 * i + (q >> 1)) * g.W + 2 * j + (q & 1));
+            uv[q] = ld8<true>(u + pix * (uint32_t)g.C + m.cg * 8);
+            bits[q] = mask[pix * (uint32_t)m.G + m.cg];
+        }
+        float gz[4][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int sh = 8 * (k & 3);
+            uint32_t c[4];
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                c[q] = ((k < 4 ? am[q].x : am[q].y) >> sh) & 0xffu;
+                v[q] = (float)gy[q][k];
+            }
+            gz[0][k] = (float)(bf16)(c[0] == 4u ? v[0] : 0.f);
+            gz[1][k] = (float)(bf16)((c[0] == 5u ? v[0] : 0.f) + (c[1] == 3u ? v[1] : 0.f));
+            gz[2][k] = (float)(bf16)((c[0] == 7u ? v[0] : 0.f) + (c[2] == 1u ? v[2] : 0.f));
+            gz[3][k] = (float)(bf16)((((c[0] == 8u ? v[0] : 0.f) + (c[1] == 6u ? v[1] : 0.f)) + (c[2] == 2u ? v[2] : 0.f)) +
+                                     (c[3] == 0u ? v[3] : 0.f));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gg = ((bits[q] >> k) & 1u) ? gz[q][k] : 0.f;
+                if (MODE == 0) {
+                    s0[k] += gg;
+                    s1[k] += gg * ((float)uv[q][k] - c1[k]) * c2[k];
+                } else {
+                    o[k] = c1[k] * gg + c2[k] * (float)uv[q][k] + c3[k];
+                }
+            }
+            if (MODE == 1) {
+                const uint32_t pix = (uint32_t)((b * g.H + 2 * i + (q >> 1)) * g.W + 2 * j + (q & 1));
+                st8<true>(du + pix * (uint32_t)g.C + m.cg * 8, o);
+            }
+        }
+    }
+    if (MODE == 0) block_reduce_store(m, g.C, s0, s1, slab);
+}
+
 int grid_for(long M, int C) {
     const int R = kThreads / (C >> 3);
     long parts = (M + (long)R * 16 - 1) / ((long)R * 16);
@@ -886,6 +979,31 @@ void launch_bn_relu_maxpool_fwd(const void* u, void* y, uint8_t* argmax, uint8_t
     if (stream_nt((long)B * H * W * C * 2)) PDT_POOLF(true);
     else PDT_POOLF(false);
 #undef PDT_POOLF
+}
+
+// -> du; slab: [parts][2][C] workspace, sums_out [2][C], coef [3][C] workspace (see launch_bn_bwd_elemt for count / mb)
+void launch_bn_relu_maxpool_bwd(const void* dy, const uint8_t* argmax, const void* u, const uint8_t* mask, void* du, int B,
+                                int H, int W, int C, int Ho, int Wo, const float* mean, const float* invstd,
+                                const float* gamma, float count, const float* count_dev, float* slab, int parts,
+                                float* sums_out, float* coef, hipStream_t s, const IpcMailboxes* mbp) {
+    // (plain pointers with unsigned 32-bit element indices: no 2 GiB window, the whole batch in one launch)
+    if ((long)B * H * W * C >= (1L << 32) || H % 2 != 0 || W % 2 != 0 || Ho != H / 2 || Wo != W / 2 || parts < 1) {
+        fprintf(stderr, "bn_relu_maxpool_bwd: unsupported geometry %d x %d -> %d x %d\n", H, W, Ho, Wo);
+        abort();
+    }
+    const IpcMailboxes mb = mbp ? *mbp : no_exchange();
+    const int R = kThreads / (C >> 3);
+    PoolGeom g = pool_geom(B, H, W, C, Ho, Wo, false);
+    g.dw = make_fastdiv((uint32_t)(W / 2));
+    g.dh = make_fastdiv((uint32_t)(H / 2));
+    const size_t lds = (size_t)kThreads * 16 * sizeof(float);
+    hipLaunchKernelGGL(k_bn_relu_maxpool_bwd<0>, dim3(parts), dim3(kThreads), lds, s, (const bf16*)dy, argmax, (const bf16*)u,
+                       mask, (bf16*)nullptr, g, mean, invstd, (const float*)nullptr, slab);
+    hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 31) / 32), dim3(kThreads), 0, s, (const float*)slab, parts, C, mean, invstd,
+                       gamma, count, count_dev, sums_out, coef, mb);
+    const long P = (long)B * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(k_bn_relu_maxpool_bwd<1>, dim3((unsigned)((P + R - 1) / R)), dim3(kThreads), 0, s, (const bf16*)dy, argmax,
+                       (const bf16*)u, mask, (bf16*)du, g, mean, invstd, (const float*)coef, (float*)nullptr);
 }
 
 }  // namespace pdt

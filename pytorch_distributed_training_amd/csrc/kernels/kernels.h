@@ -84,6 +84,12 @@ struct BnAffine {
     const float* gamma;
     const float* beta;
 };
+// backward of the fused stem tail (even H, W; Ho = H/2, Wo = W/2): both BN-backward passes gather the pooled gradient
+// themselves, the full-resolution gradient never exists.  slab [parts][2][C], sums_out [2][C], coef [3][C] workspaces.
+void launch_bn_relu_maxpool_bwd(const void* dy, const uint8_t* argmax, const void* u, const uint8_t* mask, void* du, int B,
+                                int H, int W, int C, int Ho, int Wo, const float* mean, const float* invstd,
+                                const float* gamma, float count, const float* count_dev, float* slab, int parts,
+                                float* sums_out, float* coef, hipStream_t s, const IpcMailboxes* mb = nullptr);
 void launch_bn_apply(const void* x, const void* residual, void* z, uint8_t* mask /*[M][C/8] or null*/, long M, int C,
                      const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
                      const BnAffine& res_affine, hipStream_t s);

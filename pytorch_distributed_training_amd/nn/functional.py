@@ -412,6 +412,7 @@ class _BNActFn(torch.autograd.Function):
 
 DUAL_BN_BACKWARD = os.environ.get("PDT_DUAL_BN_BACKWARD", "1") != "0"  # bn3 + downsample BN in one pass over dz
 _FUSE_BN_REDUCE = os.environ.get("PDT_FUSE_BN_REDUCE", "1") != "0"
+_FUSE_STEM_POOL_BWD = os.environ.get("PDT_FUSE_STEM_POOL_BWD", "1") != "0"  # stem tail backward without dz
 
 
 def bn_act(x, gamma, beta, cfg: BNConfig, residual=None, relu: bool = False, stats=None,
@@ -781,6 +782,14 @@ class _BNReluPoolFn(torch.autograd.Function):
     def backward(ctx, dy):
         u, y, aux, act, mean, invstd, g32, count_t = ctx.saved_tensors
         be, cfg, world, count, gdt, bdt = ctx.cfg
+        if (_FUSE_STEM_POOL_BWD and be is not reference and cfg.training and (world == 1 or ctx.ipc is not None)
+                and be.bn_relu_maxpool_bwd_ok(u)):
+            # both BN-backward passes gather the pooled gradient themselves: no full-resolution dz in memory
+            du, sums = be.bn_relu_maxpool_bwd(_cl(dy), aux, u, act, mean, invstd, g32, count_t if world > 1 else count,
+                                              ipc=ctx.ipc.native if world > 1 else None)
+            dgamma = sums[1].to(gdt) if (gdt is not None and ctx.needs_input_grad[1]) else None
+            dbeta = sums[0].to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
+            return (du if ctx.needs_input_grad[0] else None), dgamma, dbeta, None, None
         # (the oracle's pool backward recomputes the pooling from its input: hand it the activation it kept)
         dz = be.maxpool3x3s2_bwd(_cl(dy), act if be is reference else u, y, aux)
         psums = be.bn_bwd_reduce(dz, act, u, mean, invstd, True)

@@ -346,6 +346,18 @@ def maxpool3x3s2_bwd(dy, x, y, argmax):
     return _C.maxpool3x3s2_bwd(dy, argmax, list(x.shape))
 
 
+def bn_relu_maxpool_bwd_ok(u) -> bool:
+    """The gather-based backward of the fused stem tail takes even H, W and < 2^32 elements."""
+    return u.shape[2] % 2 == 0 and u.shape[3] % 2 == 0 and u.numel() < (1 << 32)
+
+
+def bn_relu_maxpool_bwd(dy, argmax, u, mask, mean, invstd, gamma, count, ipc=None):
+    """Backward of ``bn_relu_maxpool_fwd`` -> ``(du, sums [2,C])``: both BN-backward passes gather the pooled gradient
+    themselves, the full-resolution gradient is never written."""
+    c, cd = _count_args(count)
+    return _C.bn_relu_maxpool_bwd(dy, argmax, u, mask, mean, invstd, gamma.contiguous(), c, cd, ipc)
+
+
 def bn_relu_maxpool_fwd(u, mean, invstd, gamma, beta):
     """``maxpool3x3/2/1(relu(bn(u)))`` in one pass over the conv output -> (y, argmax taps uint8 [B,Ho,Wo,C],
     1-bit ReLU mask [B*H*W, C/8] of the full-resolution activation, which is never written)"""
