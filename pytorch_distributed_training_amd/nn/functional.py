@@ -857,10 +857,9 @@ def conv_bn_act(x, conv, bn, relu: bool = True, residual=None, return_skip: bool
 
     if _PLAIN_TORCH:
         # calibration mode: the same network through stock PyTorch-ROCm ops (MIOpen conv, ATen BN)
-        w = conv.weight
-        lp = getattr(w, "_lp", None)
-        w = lp if (lp is not None and lp.dtype == x.dtype) else w.to(x.dtype)
-        y = torch.nn.functional.conv2d(x, w, None, conv.stride, conv.padding)
+        # (an autograd-visible cast of the fp32 master weight, as autocast does: the detached low-precision shadow
+        # the native nodes read would leave the convolution weights without a gradient)
+        y = torch.nn.functional.conv2d(x, conv.weight.to(x.dtype), None, conv.stride, conv.padding)
         y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training,
                                            bn.momentum if bn.momentum is not None else 0.1, bn.eps)
         if residual is not None:

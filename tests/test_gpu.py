@@ -617,6 +617,35 @@ def test_dataflow_fusions_do_not_change_the_native_result(monkeypatch):
             assert err == 0.0 and cos > 0.99, (name, err, cos)
 
 
+def test_plain_torch_calibration_mode_trains_every_parameter(tmp_path):
+    """PDT_PLAIN_TORCH=1 (the same-hardware calibration row: stock MIOpen / ATen ops) must run the WHOLE training
+    step: every parameter, the convolution weights included, gets a gradient and moves.  (It once read the detached
+    bf16 shadow of the weights: no weight gradient, a calibration row that skipped a third of the work and a
+    network that did not learn -- bench/convergence.py.)"""
+    code = (
+        "import os, sys, json, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from pytorch_distributed_training_amd import dist as pdist\n"
+        "from pytorch_distributed_training_amd.engine import Engine, EngineConfig\n"
+        "pdist.init_process_group(backend='rccl', local_rank=0)\n"
+        "eng = Engine(EngineConfig(model='resnet18', num_classes=10, dtype='bf16', optimizer='sgd', lr=0.05, seed=0))\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "x = torch.rand(32, 3, 64, 64, generator=g).cuda(); y = torch.randint(0, 10, (32,), generator=g).cuda()\n"
+        "before = {n: p.detach().clone() for n, p in eng.net.module.named_parameters()}\n"
+        "losses = [float(eng.train_step(x, y)) for _ in range(6)]\n"
+        "nograd = [n for n, p in eng.net.module.named_parameters() if p.grad is None or float(p.grad.abs().sum()) == 0.0]\n"
+        "still = [n for n, p in eng.net.module.named_parameters() if torch.equal(p.detach(), before[n])]\n"
+        "print(json.dumps({'losses': losses, 'nograd': nograd, 'still': still}))\n"
+    ) % ROOT
+    env = dict(os.environ, PDT_PLAIN_TORCH="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29553", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["nograd"] == [] and out["still"] == [], out
+    assert out["losses"][-1] < out["losses"][0] - 0.3, out
+
+
 def test_reducer_runs_the_rccl_path_with_a_size1_communicator(tmp_path):
     """The multi-GPU hot path (multi-tensor flatten -> fence -> ncclAllReduce on the communicator's stream ->
     per-bucket event -> optimizer) on one GPU: PDT_FORCE_COMM=1 gives the C++ reducer a size-1 communicator, and
