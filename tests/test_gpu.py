@@ -369,7 +369,7 @@ def _engine(model="resnet50", dtype="bf16", **kw):
     os.environ.setdefault("MASTER_PORT", "29541")
     if not pdist.is_initialized():
         pdist.init_process_group(backend="rccl", local_rank=0)
-    return Engine(EngineConfig(model=model, num_classes=kw.pop("num_classes", 1000), dtype=dtype, seed=0, **kw))
+    return Engine(EngineConfig(model=model, num_classes=kw.pop("num_classes", 1000), dtype=dtype, seed=kw.pop("seed", 0), **kw))
 
 
 def test_resnet50_bf16_step_loss_decreases_on_fixed_batch():
@@ -615,6 +615,34 @@ def test_dataflow_fusions_do_not_change_the_native_result(monkeypatch):
             assert err < 0.05 and cos > 0.9, (name, err, cos)
         else:
             assert err == 0.0 and cos > 0.99, (name, err, cos)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_checkpoint_resume_on_the_native_path_is_bit_exact(tmp_path, opt):
+    """SURVEY 5.4 on the GPU path: fp32 master weights in the arena, their bf16 shadows, BN running statistics and
+    the optimizer state go through a checkpoint; a fresh engine (other seed) that loads it continues with the losses
+    of the uninterrupted run, bit for bit (the kernels are deterministic)."""
+    from pytorch_distributed_training_amd.utils import checkpoint as ckpt
+
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.rand(16, 3, 64, 64, generator=g).cuda() for _ in range(5)]
+    ys = [torch.randint(0, 10, (16,), generator=g).cuda() for _ in range(5)]
+    kw = dict(model="resnet18", num_classes=10, optimizer=opt, lr=0.01 if opt == "sgd" else 1e-3)
+    a = _engine(**kw)
+    first = [float(a.train_step(xs[i], ys[i])) for i in range(3)]
+    path = str(tmp_path / "ck.pt")
+    assert ckpt.save_checkpoint(path, a.net, a.optimizer, epoch=0, global_step=3)
+    rest = [float(a.train_step(xs[i], ys[i])) for i in range(3, 5)]
+    b = _engine(seed=123, **kw)
+    w0 = b.net.module.layer1[0].conv1.weight
+    assert not torch.equal(w0.detach(), a.net.module.layer1[0].conv1.weight.detach())
+    st = ckpt.load_checkpoint(path, b.net, b.optimizer)
+    assert st["global_step"] == 3
+    assert torch.equal(w0._lp, w0.detach().to(torch.bfloat16))  # shadows refreshed from the loaded masters
+    resumed = [float(b.train_step(xs[i], ys[i])) for i in range(3, 5)]
+    assert resumed == rest, (first, rest, resumed)
+    for (n, p), q in zip(a.net.module.state_dict().items(), b.net.module.state_dict().values()):
+        assert torch.equal(p, q), n
 
 
 def test_plain_torch_calibration_mode_trains_every_parameter(tmp_path):
