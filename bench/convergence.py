@@ -63,7 +63,8 @@ def run_one(args) -> dict:
     pdist.init_process_group(backend="rccl" if gpu else "gloo", local_rank=0)
     dtype = BACKENDS[args.backend][1] if gpu else "fp32"
     eng = Engine(EngineConfig(model=args.model, num_classes=args.num_classes, dtype=dtype, optimizer=args.optimizer,
-                              lr=args.lr, sync_bn=True, seed=args.seed, image_size=args.image_size))
+                              lr=args.lr, sync_bn=True, seed=args.seed, image_size=args.image_size,
+                              graph=bool(args.graph) and gpu, grad_dtype=args.grad_dtype))
     sample = make_batches(args.num_classes, args.image_size, seed=1)
     gen = torch.Generator().manual_seed(2 + 10 * args.seed)
     held = torch.Generator().manual_seed(3)
@@ -71,7 +72,7 @@ def run_one(args) -> dict:
     losses, t0 = [], time.time()
     for step in range(args.steps):
         x, y = sample(args.batch_size, gen, args.noise)
-        losses.append(eng.train_step(x.to(eng.device), y.to(eng.device)))
+        losses.append(eng.train_step(x.to(eng.device), y.to(eng.device)).clone())  # (a graph replay returns its static buffer)
         if (step + 1) % args.window == 0:
             print(f"[{args.backend}] step {step + 1}: loss {float(torch.stack(losses[-args.window:]).mean()):.4f}",
                   file=sys.stderr, flush=True)
@@ -79,7 +80,7 @@ def run_one(args) -> dict:
     acc = eng.evaluate(eval_set)
     curve = [sum(losses[i:i + args.window]) / len(losses[i:i + args.window]) for i in range(0, len(losses), args.window)]
     out = {"backend": args.backend, "dtype": dtype, "model": args.model, "image_size": args.image_size,
-           "batch_size": args.batch_size, "steps": args.steps, "optimizer": args.optimizer, "lr": args.lr, "seed": args.seed,
+           "batch_size": args.batch_size, "steps": args.steps, "optimizer": args.optimizer, "lr": args.lr, "seed": args.seed, "graph": bool(eng._graph is not None), "grad_dtype": args.grad_dtype,
            "first_loss": losses[0], "loss_curve": [round(v, 4) for v in curve], "eval_top1": round(acc, 4),
            "finite": all(v == v and abs(v) != float("inf") for v in losses), "seconds": round(time.time() - t0, 1)}
     eng.close()
@@ -101,6 +102,8 @@ def main() -> int:
     ap.add_argument("--optimizer", default="adam")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--noise", type=float, default=0.25)
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a hipGraph (what main.py does by default)")
+    ap.add_argument("--grad_dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient buckets")
     ap.add_argument("--seed", type=int, default=0, help="initial weights and order of the training samples")
     ap.add_argument("--timeout", type=int, default=500)
     args = ap.parse_args()

@@ -1202,9 +1202,17 @@ const Table& get_table(const std::vector<std::vector<const Tensor*>>& cols, cons
     t.ntensors = (int)n;
     t.nchunks = (int)chunks.size();
     host.insert(host.end(), chunks.begin(), chunks.end());
-    Tensor cpu = at::empty({(long)host.size()}, at::TensorOptions().dtype(at::kLong));
-    std::memcpy(cpu.data_ptr<int64_t>(), host.data(), host.size() * sizeof(int64_t));
-    t.dev = cpu.to(dev);
+    // uploaded through kernel arguments, not a host-to-device copy: a table can be missed inside a hipGraph capture
+    // (gradients that are not bucket views are re-allocated from the graph's pool), where a copy from pageable
+    // memory is not permitted
+    t.dev = at::empty({(long)host.size()}, at::TensorOptions().dtype(at::kLong).device(dev));
+    hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
+    for (size_t off = 0; off < host.size(); off += kTableWords) {
+        TableWords tw{};
+        const int cnt = (int)std::min<size_t>(kTableWords, host.size() - off);
+        std::memcpy(tw.w, host.data() + off, cnt * sizeof(int64_t));
+        launch_write_words(tw, cnt, t.dev.data_ptr<int64_t>() + off, stream);
+    }
     t.key = std::move(key);
     auto& slot = g_tables[h];
     slot = std::move(t);

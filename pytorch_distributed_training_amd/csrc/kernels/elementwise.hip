@@ -313,6 +313,11 @@ __global__ __launch_bounds__(256) void k_multi_transpose_ntc(const TransposeArgs
     }
 }
 
+__global__ __launch_bounds__(64) void k_write_words(const TableWords t, int n, int64_t* __restrict__ dst) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) dst[i] = t.w[i];
+}
+
 // out[y][j] = sum over the parts of chunk y of slab[p*stride + j].  Block = 64 column quads x 4
 // part lanes; grid = (column blocks of 256, part chunks).  Deterministic (no atomics).
 __global__ __launch_bounds__(256) void k_reduce_slab(const float* __restrict__ slab, int nparts, long stride, int n,
@@ -412,6 +417,11 @@ void launch_multi_flatten(const int64_t* table, int ntensors, int nchunks, float
         hipLaunchKernelGGL((k_multi_flatten<bf16, float>), grid, block, 0, s, table, ntensors, scale);
     else
         hipLaunchKernelGGL((k_multi_flatten<bf16, bf16>), grid, block, 0, s, table, ntensors, scale);
+}
+
+void launch_write_words(const TableWords& t, int n, int64_t* dst, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_write_words, dim3((n + 63) / 64), dim3(64), 0, s, t, n, dst);
 }
 
 void launch_flatten_args(const FlatArgs& a, float scale, int src_dtype, int dst_dtype, hipStream_t s) {

@@ -27,6 +27,13 @@ struct FlatArgs {
     int n;
 };
 void launch_flatten_args(const FlatArgs& a, float scale, int src_dtype, int dst_dtype, hipStream_t s);
+// A host table travels to the device in the ARGUMENTS of a tiny kernel (no host-to-device copy: legal while the
+// stream is being captured into a hipGraph, and the graph keeps the words).
+constexpr int kTableWords = 448;
+struct TableWords {
+    int64_t w[kTableWords];
+};
+void launch_write_words(const TableWords& t, int n, int64_t* dst, hipStream_t s);
 void launch_multi_adam(const int64_t* table, int ntensors, int nchunks, float lr, float beta1, float beta2,
                        float eps, float weight_decay, float bias_corr1, float bias_corr2_sqrt,
                        const float* step_dev /* non-null: bias corrections from this device step count */,

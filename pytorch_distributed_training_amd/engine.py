@@ -118,7 +118,8 @@ class Engine:
     # ------------------------------------------------------------------ step
     def train_step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         """One iteration in the reference's order; returns the local loss tensor
-        (fp32 scalar on the device, not synchronised with the host)."""
+        (fp32 scalar on the device, not synchronised with the host).  Under ``graph=True`` this is the replayed
+        graph's static output buffer: read or clone it before the next step overwrites it."""
         if self.cfg.graph and self.device.type == "cuda" and self._graph_failed is None:
             loss = self._graph_step(imgs, labels)
         else:

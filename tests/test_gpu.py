@@ -822,16 +822,19 @@ def test_bf16_gradient_buckets_follow_the_fp32_run():
     assert runs["bf16"][-1] < 0.5 * runs["bf16"][0] and runs["fp32"][-1] < 0.5 * runs["fp32"][0]
 
 
-@pytest.mark.parametrize("opt", ["sgd", "adam"])
-def test_hip_graph_step_matches_eager(opt):
+@pytest.mark.parametrize("opt,gd", [("sgd", "fp32"), ("adam", "fp32"), ("adam", "bf16")])
+def test_hip_graph_step_matches_eager(opt, gd):
     """Engine(graph=True) captures forward+backward+optimizer after 3 eager steps; replays must produce the same
-    losses as the eager engine (Adam's bias correction comes from the device-side step counter)."""
+    losses as the eager engine (Adam's bias correction comes from the device-side step counter).  With bf16 gradient
+    buckets the fp32 ``.grad`` tensors are not bucket views: the capture allocates them anew, and the optimizer's
+    pointer table for them is uploaded through kernel arguments (a host-to-device copy is not capturable)."""
     g = torch.Generator().manual_seed(0)
     xs = [torch.rand(32, 3, 32, 32, generator=g).cuda() for _ in range(2)] * 4  # two alternating batches
     ys = [torch.randint(0, 10, (32,), generator=g).cuda() for _ in range(2)] * 4
     runs = []
     for graph in (False, True):
-        eng = _engine(model="resnet18", num_classes=10, optimizer=opt, lr=0.01 if opt == "sgd" else 1e-3, graph=graph)
+        eng = _engine(model="resnet18", num_classes=10, optimizer=opt, lr=0.01 if opt == "sgd" else 1e-3, graph=graph,
+                      grad_dtype=gd)
         eng.optimizer.set_capturable(True)  # same (device-side) bias-correction arithmetic in both runs
         losses = [float(eng.train_step(x, y)) for x, y in zip(xs, ys)]
         runs.append(losses)
