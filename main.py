@@ -95,6 +95,10 @@ def main(argv=None) -> int:
     trainset = build_dataset(args.dataset, train=True, root=args.data_root, length=args.dataset_len)
     valset = build_dataset(args.dataset, train=False, root=args.data_root,
                            length=None if args.dataset_len is None else max(1, args.dataset_len // 5))
+    ds_classes = getattr(trainset, "num_classes", None)
+    if ds_classes is not None and ds_classes > args.num_classes:
+        raise SystemExit(f"--num_classes {args.num_classes} is narrower than the {ds_classes} classes of --dataset "
+                         f"{args.dataset}: labels would fall outside the classifier head")
     sampler = DistributedSampler(trainset)
     train_loader = DataLoader(trainset, batch_size=batch_size, shuffle=False, pin_memory=True, sampler=sampler,
                               device=env.device)

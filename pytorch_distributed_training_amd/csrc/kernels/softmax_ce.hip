@@ -4,7 +4,8 @@
 // [B, 1000] logits (main.py:79,101,103).  Here one wave (64 lanes) owns a row: row max,
 // sum-exp, the row's loss and dlogits = (softmax - onehot) / B are produced from a single
 // read of the row kept in registers; a second tiny launch averages the per-row losses
-// (deterministic, no float atomics).
+// (deterministic, no float atomics).  A label outside [0, N) makes the row's loss, and with it the mean, NaN
+// (ATen raises a device-side assertion there): never an out-of-bounds read, never a silently wrong number.
 #include "common.h"
 #include "kernels.h"
 
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void k_softmax_ce(const T* __restrict__ logits
             const int j = lane + k * 64;
             if (j < N) dx[j] = (T)((v[k] * inv - (j == label ? 1.f : 0.f)) * invB);
         }
-        if (lane == 0) row_loss[row] = __logf(se) + mx - ((label >= 0 && label < N) ? (float)x[label] : 0.f);
+        if (lane == 0) row_loss[row] = __logf(se) + mx - ((label >= 0 && label < N) ? (float)x[label] : __builtin_nanf(""));
     } else {
         float mx = -INFINITY;
         for (int j = lane; j < N; j += 64) mx = fmaxf(mx, (float)x[j]);
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void k_softmax_ce(const T* __restrict__ logits
         const float inv = 1.f / se;
         for (int j = lane; j < N; j += 64)
             dx[j] = (T)((__expf((float)x[j] - mx) * inv - (j == label ? 1.f : 0.f)) * invB);
-        if (lane == 0) row_loss[row] = __logf(se) + mx - ((label >= 0 && label < N) ? (float)x[label] : 0.f);
+        if (lane == 0) row_loss[row] = __logf(se) + mx - ((label >= 0 && label < N) ? (float)x[label] : __builtin_nanf(""));
     }
 }
 

@@ -279,6 +279,12 @@ def gemm_nt(a, w, bias=None, residual=None, gelu_in=None, act: int = 0, want_pre
     bias fp32 (added before the rounding), ``act=1`` GELU, ``residual`` added last, ``gelu_in``: the result is
     multiplied by GELU'(gelu_in); ``colsum``: fp32 column sums of ``c``."""
     b32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float()).contiguous()
+    k = a.shape[-1]
+    if k % 64 and (residual is not None or gelu_in is not None or act):
+        # the ragged-K build of the kernel carries no residual / GELU epilogue (hidden sizes of real transformers
+        # are multiples of 64; this is a toy width): zero columns up to the next K-tile change nothing in the product
+        pad = (0, 64 - k % 64)
+        a, w = torch.nn.functional.pad(_mat(a), pad), torch.nn.functional.pad(_mat(w), pad)
     return _C.gemm_nt(_mat(a), _mat(w), b32, None if residual is None else _mat(residual),
                       None if gelu_in is None else _mat(gelu_in), act, want_preact, want_colsum)
 

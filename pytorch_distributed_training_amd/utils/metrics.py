@@ -30,6 +30,7 @@ class ThroughputLog:
     def __init__(self, job_id: str, batch_size: int, global_rank: int, world_size: int, directory: str = "."):
         import os
 
+        os.makedirs(directory or ".", exist_ok=True)  # (every rank writes its own file; a missing --log_dir is created)
         self.path = os.path.join(directory, log_file_name(job_id, batch_size, global_rank))
         self.batch_size, self.rank, self.world = batch_size, global_rank, world_size
         self.f = open(self.path, "w")

@@ -237,6 +237,22 @@ def test_ordered_shutdown_two_ranks(free_port, tmp_path):
     assert all(l == l for r in res for l in r["losses"])
 
 
+def test_main_py_refuses_a_head_narrower_than_the_label_range_and_creates_log_dir(tmp_path, free_port, repo_root):
+    """Two usability faults bench/cli_matrix.sh found: a classifier head narrower than the dataset's labels trained
+    on garbage (now refused up front), and a ``--log_dir`` that did not exist yet crashed the throughput log."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               PYTHONPATH=str(repo_root))
+    base = [sys.executable, os.path.join(str(repo_root), "main.py"), "--backend", "gloo", "--model", "resnet18", "--batch_size", "8",
+            "--dataset_len", "32", "--epochs", "1", "--steps", "2", "--profile", "none"]
+    r = subprocess.run(base + ["--dataset", "synthetic-cifar", "--num_classes", "10"], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "narrower than the 100 classes" in r.stderr, r.stderr[-2000:]
+    r = subprocess.run(base + ["--dataset", "synthetic-cifar10", "--num_classes", "10", "--log_dir", "logs/a/b"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (tmp_path / "logs" / "a" / "b" / "Job0_8_0.log").exists()
+
+
 def test_main_py_mid_epoch_resume_matches_uninterrupted_run(tmp_path, free_port, repo_root):
     """--checkpoint_every saves a position INSIDE the epoch; --resume continues from it: same number of steps in
     total, same final parameters as the run that was never interrupted."""

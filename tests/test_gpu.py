@@ -617,6 +617,48 @@ def test_dataflow_fusions_do_not_change_the_native_result(monkeypatch):
             assert err == 0.0 and cos > 0.99, (name, err, cos)
 
 
+def test_toy_transformer_widths_stay_on_the_native_gemm():
+    """``vit_tiny_test`` (hidden 32, MLP 64: reductions shorter than one K-tile, with residual / GELU epilogues) once
+    aborted in the GEMM launcher ("unsupported epilogue combination", found by bench/cli_matrix.sh): the ragged-K
+    build has no residual / GELU epilogue, so such operands are zero-padded to the K-tile."""
+    from pytorch_distributed_training_amd.nn import functional as pF
+    from pytorch_distributed_training_amd.ops import native
+
+    a = (torch.randn(100, 40, device="cuda") * 0.5).to(torch.bfloat16)
+    w = (torch.randn(48, 40, device="cuda") * 0.2).to(torch.bfloat16)
+    res = torch.randn(100, 48, device="cuda").to(torch.bfloat16)
+    bias = torch.randn(48, device="cuda")
+    want = a.float() @ w.float().t() + bias + res.float()
+    got = native.gemm_nt(a, w, bias, res)[0]
+    assert (got.float() - want).abs().max() < 0.06
+    h, u, _ = native.gemm_nt(a, w, bias, None, None, 1, True)
+    assert (u.float() - (want - res.float())).abs().max() < 0.06
+    assert (h.float() - torch.nn.functional.gelu(u.float())).abs().max() < 0.03
+    before = dict(pF.fallback_counts)
+    eng = _engine(model="vit_tiny_test", num_classes=10, optimizer="adamw", lr=1e-2, sync_bn=False)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(16, 3, 32, 32, generator=g).cuda()
+    y = torch.randint(0, 10, (16,), generator=g).cuda()
+    losses = [float(eng.train_step(x, y)) for _ in range(10)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0] - 0.3, losses
+    new = {k: v - before.get(k, 0) for k, v in pF.fallback_counts.items() if v != before.get(k, 0)}
+    assert not any(k.startswith(("linear", "mlp_gelu")) for k in new), new  # (head_dim 16 attention is the oracle's)
+
+
+def test_label_outside_the_head_makes_the_loss_nan():
+    """ATen raises a device-side assertion for a label >= classes; the fused loss kernel reads nothing out of
+    bounds and returns NaN, so that a head narrower than the dataset's label range cannot train on garbage."""
+    from pytorch_distributed_training_amd.ops import native
+
+    logits = torch.randn(8, 16, device="cuda").to(torch.bfloat16)
+    labels = torch.randint(0, 16, (8,), device="cuda")
+    loss, _ = native.softmax_ce_fwd_bwd(logits, labels)
+    assert float(loss) == float(loss)
+    labels[3] = 16
+    loss, dl = native.softmax_ce_fwd_bwd(logits, labels)
+    assert float(loss) != float(loss) and bool(torch.isfinite(dl.float()).all())
+
+
 @pytest.mark.parametrize("opt", ["sgd", "adam"])
 def test_checkpoint_resume_on_the_native_path_is_bit_exact(tmp_path, opt):
     """SURVEY 5.4 on the GPU path: fp32 master weights in the arena, their bf16 shadows, BN running statistics and
