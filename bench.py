@@ -44,8 +44,10 @@ def main(argv=None) -> int:
     # equal batch chunks; 2560 = two chunks of 1280 for the widest layers is the measured optimum (end of round 2:
     # 14.7k img/s at 1280, 14.8k at 2048, 15.0k at 2304, 15.1-15.2k at 2560, 14.8k at 3072, 14.6-14.7k at 4096 / 5120);
     # every conv launch has >12 rounds of tiles per CU and the gradient all-reduce is <1 % of the step.
-    ap.add_argument("--batch_size", type=int, default=2560,
-                    help="per-GPU batch; 0 = size it from the memory model (utils/memory.py)")
+    # Any other network / image size without --batch_size: the memory model's pick at the same ~40 % of the device.
+    ap.add_argument("--batch_size", type=int, default=None,
+                    help="per-GPU batch (default: 2560 for ResNet-50 at 224x224, else the memory model's pick at 40 %% "
+                         "of the device, at most 2560); 0 = the memory model's pick at 85 %% (utils/memory.py)")
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--image_size", type=int, default=224)
     ap.add_argument("--num_classes", type=int, default=1000)
@@ -87,10 +89,17 @@ def main(argv=None) -> int:
         sync_bn=args.sync_bn, bucket_cap_mb=args.bucket_cap_mb, grad_dtype=args.grad_dtype, reducer=args.reducer, seed=0, graph=args.graph,
         image_size=args.image_size))
     batch_model = None
-    if args.batch_size <= 0:
+    flagship = args.model == "resnet50" and args.image_size == 224
+    if args.batch_size is None and (flagship or not on_gpu):
+        args.batch_size = 2560 if on_gpu else 32
+    if args.batch_size is None or args.batch_size <= 0:
         from pytorch_distributed_training_amd.utils.memory import suggest_batch
 
-        batch_model = suggest_batch(engine, (3, args.image_size, args.image_size), args.num_classes)
+        shape = (3, args.image_size, args.image_size)
+        if args.batch_size is None:  # a deeper / wider network at 2560 images may not fit: same share of the device
+            batch_model = suggest_batch(engine, shape, args.num_classes, fraction=0.4, cap=2560)
+        else:
+            batch_model = suggest_batch(engine, shape, args.num_classes)
         args.batch_size = batch_model["batch"]
     loader = SyntheticDeviceLoader(args.batch_size, (3, args.image_size, args.image_size), args.num_classes,
                                    device=env.device, dtype=torch.float32, ring=2, seed=env.rank)
