@@ -10,8 +10,9 @@ MI355X design: a background thread assembles batch ``t+1`` into a ring of
 pinned host buffers while step ``t`` runs; when ``device`` is given the H2D
 copy of batch ``t+1`` is issued on a dedicated HIP copy stream and fenced to
 the compute stream with an event, so the copy overlaps compute instead of
-stalling the step.  Order, batch boundaries and the short last batch are
-identical to the reference loader.
+stalling the step.  Batches bound for a GPU travel as uint8 NHWC (a quarter of
+the bytes; the device-side cast kernel does /255, bf16 and the layout).  Order,
+batch boundaries and the short last batch are identical to the reference loader.
 """
 from __future__ import annotations
 
@@ -47,7 +48,8 @@ class _RandomSampler(_SequentialSampler):
 class DataLoader:
     def __init__(self, dataset, batch_size: int = 1, shuffle: bool = False, sampler: Iterable[int] | None = None,
                  drop_last: bool = False, pin_memory: bool = False, prefetch: int = 2,
-                 device: torch.device | str | None = None, collate_fn=None, start_sample: int = 0):
+                 device: torch.device | str | None = None, collate_fn=None, start_sample: int = 0,
+                 raw_u8: bool | None = None):
         if sampler is not None and shuffle:
             raise ValueError("sampler option is mutually exclusive with shuffle")
         self.dataset = dataset
@@ -62,6 +64,11 @@ class DataLoader:
             self.device = None
         self.collate_fn = collate_fn or default_collate
         self.start_sample = int(start_sample)  # mid-epoch resume: skip this many samples once
+        # uint8 NHWC batches (the decoded-image layout) when they go to a GPU: a quarter of the host gather, the pinned
+        # ring and the H2D bytes; /255 + bf16 + layout happen in the engine's one cast kernel on the device
+        # (Engine.prepare_input).  Off for host-side consumers, which expect ToTensor's fp32 NCHW.
+        can_raw = hasattr(dataset, "get_batch") and hasattr(dataset, "images") and self.collate_fn is default_collate
+        self.raw_u8 = (self.device is not None and can_raw) if raw_u8 is None else (bool(raw_u8) and can_raw)
         self._ring: list[tuple[torch.Tensor, torch.Tensor]] = []
         self._slot_events: dict[int, "torch.cuda.Event"] = {}  # H2D completion per pinned slot
         self._copy_stream = None
@@ -103,6 +110,12 @@ class DataLoader:
     def _host_batch_impl(self, indices: list[int], slot: int):
         fast = hasattr(self.dataset, "get_batch") and self.collate_fn is default_collate
         if fast:
+            if self.raw_u8:
+                if self.pin_memory:
+                    c, h, w = self.dataset.sample_shape
+                    out, out_l = self._ring_slot(slot, (h, w, c), torch.uint8)
+                    return self.dataset.get_batch(indices, out=out, out_labels=out_l, raw_u8=True)
+                return self.dataset.get_batch(indices, raw_u8=True)
             if self.pin_memory:
                 out, out_l = self._ring_slot(slot, self.dataset.sample_shape, torch.float32)
                 return self.dataset.get_batch(indices, out=out, out_labels=out_l)

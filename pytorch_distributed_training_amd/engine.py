@@ -113,7 +113,9 @@ class Engine:
                 return imgs
             scale = 1.0 / 255.0 if imgs.dtype == torch.uint8 else 1.0
             return backend_for(imgs).nchw_to_nhwc_lowp(imgs, self.dtype, scale)
-        return imgs.float() / 255.0 if imgs.dtype == torch.uint8 else imgs
+        if imgs.dtype == torch.uint8:  # NHWC block from the loader -> ToTensor's fp32 NCHW in [0, 1]
+            return imgs.permute(0, 3, 1, 2).float() / 255.0
+        return imgs
 
     # ------------------------------------------------------------------ step
     def train_step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:

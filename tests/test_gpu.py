@@ -645,6 +645,33 @@ def test_toy_transformer_widths_stay_on_the_native_gemm():
     assert not any(k.startswith(("linear", "mlp_gelu")) for k in new), new  # (head_dim 16 attention is the oracle's)
 
 
+def test_loader_sends_uint8_batches_and_the_cast_kernel_matches_the_fp32_path():
+    """The loader's GPU path: uint8 NHWC through the pinned ring and the copy stream, /255 + bf16 + layout in the
+    engine's one cast kernel; same tensor as the fp32 NCHW path gives, same order, short last batch."""
+    from pytorch_distributed_training_amd.data import DataLoader
+    from pytorch_distributed_training_amd.data.datasets import SyntheticImageNet
+
+    ds = SyntheticImageNet(train=True, num_classes=10, length=20, pool=20, image_size=64)
+    eng = _engine(model="resnet18", num_classes=10, optimizer="sgd", lr=0.01)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    fast = DataLoader(ds, batch_size=8, pin_memory=True, device=dev)
+    slow = DataLoader(ds, batch_size=8, pin_memory=True, device=dev, raw_u8=False)
+    assert fast.raw_u8 and not slow.raw_u8
+    n = 0
+    for (xu, yu), (xf, yf) in zip(fast, slow):
+        assert xu.dtype == torch.uint8 and xu.is_cuda and tuple(xu.shape[1:]) == (64, 64, 3)
+        assert xf.dtype == torch.float32 and tuple(xf.shape[1:]) == (3, 64, 64)
+        a, b = eng.prepare_input(xu), eng.prepare_input(xf)
+        assert a.dtype == torch.bfloat16 and a.is_contiguous(memory_format=torch.channels_last) and a.shape == b.shape
+        assert (a.float() - b.float()).abs().max() <= 2 ** -8  # (x * (1/255) vs x / 255 before the bf16 rounding)
+        assert torch.equal(yu, yf)
+        n += xu.shape[0]
+    assert n == 20
+    x, y = next(iter(fast))
+    loss = float(eng.train_step(x, y))  # the uint8 batch goes through the step as it is
+    assert loss == loss and loss < 20.0
+
+
 def test_label_outside_the_head_makes_the_loss_nan():
     """ATen raises a device-side assertion for a label >= classes; the fused loss kernel reads nothing out of
     bounds and returns NaN, so that a head narrower than the dataset's label range cannot train on garbage."""

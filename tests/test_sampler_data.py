@@ -152,3 +152,24 @@ def test_loader_rejects_sampler_and_shuffle():
     ds = SyntheticCIFAR(length=8)
     with pytest.raises(ValueError):
         DataLoader(ds, batch_size=2, shuffle=True, sampler=DistributedSampler(ds, 1, 0))
+
+
+def test_loader_raw_uint8_batches_match_the_totensor_path():
+    """Batches bound for a GPU travel as uint8 NHWC; Engine.prepare_input turns them into what the fp32 path gives."""
+    import torch
+
+    from pytorch_distributed_training_amd.data import DataLoader
+    from pytorch_distributed_training_amd.data.datasets import SyntheticCIFAR
+    from pytorch_distributed_training_amd.engine import Engine
+
+    ds = SyntheticCIFAR(train=True, num_classes=10, length=50)
+    a = list(DataLoader(ds, batch_size=16))
+    b = list(DataLoader(ds, batch_size=16, raw_u8=True))
+    assert DataLoader(ds, batch_size=16).raw_u8 is False  # host-side consumers keep ToTensor's fp32 NCHW
+    assert len(a) == len(b) == 4 and b[0][0].dtype == torch.uint8 and tuple(b[0][0].shape) == (16, 32, 32, 3)
+    assert tuple(b[-1][0].shape) == (2, 32, 32, 3)  # short last batch
+    eng = Engine.__new__(Engine)
+    eng.device, eng.dtype = torch.device("cpu"), torch.float32
+    for (xa, ya), (xb, yb) in zip(a, b):
+        assert torch.equal(ya, yb)
+        assert torch.allclose(Engine.prepare_input(eng, xb), xa, atol=1e-7)
