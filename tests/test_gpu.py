@@ -672,6 +672,40 @@ def test_loader_sends_uint8_batches_and_the_cast_kernel_matches_the_fp32_path():
     assert loss == loss and loss < 20.0
 
 
+def test_no_sync_accumulates_gradients_on_the_native_path():
+    """Gradient accumulation (``DistributedDataParallel.no_sync``) with bucket-view gradients on the GPU: a backward
+    inside no_sync followed by a synchronised one leaves grad(x1) + grad(x2) in ``.grad``."""
+    eng = _engine(model="resnet18", num_classes=10, optimizer="sgd", lr=0.0)
+    net, crit = eng.net, eng.criterion
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.rand(16, 3, 64, 64, generator=g).cuda() for _ in range(2)]
+    ys = [torch.randint(0, 10, (16,), generator=g).cuda() for _ in range(2)]
+
+    def fb(i):
+        crit(net(eng.prepare_input(xs[i])), ys[i]).backward()
+
+    def grads():
+        return [p.grad.detach().float().clone() for p in net.parameters()]
+
+    fb(0)  # warm-up iteration: the reducer rebuilds its buckets after the first synchronised backward
+    eng.optimizer.zero_grad()
+    fb(0)
+    g1 = grads()
+    eng.optimizer.zero_grad()
+    fb(1)
+    g2 = grads()
+    eng.optimizer.zero_grad()
+    with net.no_sync():
+        fb(0)
+    fb(1)
+    acc = grads()
+    buckets = {t.untyped_storage().data_ptr() for t in net.reducer.bucket_tensors()}
+    assert all(p.grad.untyped_storage().data_ptr() in buckets for p in net.parameters())
+    for a, b, c, (n, _) in zip(acc, g1, g2, net.module.named_parameters()):
+        want = b + c
+        assert (a - want).abs().max() <= 1e-3 * float(want.abs().max()) + 1e-6, n
+
+
 def test_label_outside_the_head_makes_the_loss_nan():
     """ATen raises a device-side assertion for a label >= classes; the fused loss kernel reads nothing out of
     bounds and returns NaN, so that a head narrower than the dataset's label range cannot train on garbage."""
