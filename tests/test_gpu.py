@@ -706,6 +706,39 @@ def test_no_sync_accumulates_gradients_on_the_native_path():
         assert (a - want).abs().max() <= 1e-3 * float(want.abs().max()) + 1e-6, n
 
 
+@pytest.mark.parametrize("model,size", [("resnet50", 96), ("resnet18", 64)])
+def test_eval_mode_on_the_native_path_matches_the_oracle(model, size):
+    """Inference (``net.eval()``: BN with running statistics, no autograd) through the HIP kernels against the same
+    network run through the fp32 oracle ops, after a few training steps have moved the running statistics."""
+    from pytorch_distributed_training_amd import ops
+
+    eng = _engine(model=model, num_classes=10, optimizer="sgd", lr=0.01)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(16, 3, size, size, generator=g).cuda()
+    y = torch.randint(0, 10, (16,), generator=g).cuda()
+    for _ in range(3):
+        eng.train_step(x, y)
+    rm = eng.net.module.bn1.running_mean.float()
+    assert float(rm.abs().sum()) > 0
+    eng.net.eval()
+    try:
+        with torch.no_grad():
+            xb = eng.prepare_input(x)
+            out = eng.net(xb).float()
+            ops.set_force_reference(True)
+            try:
+                ref = eng.net(xb).float()
+            finally:
+                ops.set_force_reference(False)
+    finally:
+        eng.net.train()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max() < 0.05 * max(1.0, float(ref.abs().max())), float((out - ref).abs().max())
+    assert torch.equal(eng.net.module.bn1.running_mean.float(), rm)  # eval does not touch the running statistics
+    acc = eng.evaluate([(x, y)])
+    assert 0.0 <= acc <= 1.0
+
+
 def test_label_outside_the_head_makes_the_loss_nan():
     """ATen raises a device-side assertion for a label >= classes; the fused loss kernel reads nothing out of
     bounds and returns NaN, so that a head narrower than the dataset's label range cannot train on garbage."""
