@@ -88,3 +88,31 @@ def test_rccl_busbw_calibration_feeds_the_scaling_model(tmp_path, free_port):
     res = json.loads(out.stdout)
     assert res["link_GBps"] == doc["link_GBps"] and res["constants"].startswith("calibrated")
     assert [r["n_gpus"] for r in res["ring"]] == [1, 2, 4, 8]
+
+
+def test_convergence_script_runs_on_cpu(tmp_path):
+    """bench/convergence.py (native vs stock vs oracle learning curves on the GPU) stays runnable: on CPU every back
+    end is the fp32 oracle, so the rows must agree exactly."""
+    import json
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench", "convergence.py"), "--model", "resnet18", "--steps", "4",
+                        "--window", "2", "--eval_batches", "1", "--batch_size", "8", "--num_classes", "10",
+                        "--backends", "native,oracle"], cwd=tmp_path, env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert [r["backend"] for r in rows] == ["native", "oracle"] and all(r["finite"] for r in rows)
+    assert rows[0]["loss_curve"] == rows[1]["loss_curve"] and "held-out top-1" in p.stdout
+
+
+def test_cli_matrix_verdict_line(tmp_path):
+    (tmp_path / "s.json").write_text('{"images_per_sec_synchronised": 123.456, "hip_graph": true, "reducer": "native"}')
+    (tmp_path / "s.log").write_text("Epoch: 0 step: 0 loss: 4.5\nEpoch: 0 step: 10 loss: 0.5\n")
+    v = os.path.join(ROOT, "bench", "cli_matrix_verdict.py")
+    p = subprocess.run([sys.executable, v, str(tmp_path / "s.json"), str(tmp_path / "s.log")], capture_output=True, text=True)
+    assert p.stdout.startswith("OK loss 4.5 -> 0.5") and '"hip_graph": true' in p.stdout
+    (tmp_path / "s.log").write_text("Epoch: 0 step: 0 loss: 4.5\nEpoch: 0 step: 10 loss: nan\n")
+    p = subprocess.run([sys.executable, v, str(tmp_path / "s.json"), str(tmp_path / "s.log")], capture_output=True, text=True)
+    assert p.stdout.startswith("CHECK")
+    p = subprocess.run([sys.executable, v, str(tmp_path / "missing.json"), str(tmp_path / "s.log"), "finite-only"],
+                       capture_output=True, text=True)
+    assert p.stdout.startswith("CHECK") and "missing" in p.stdout
