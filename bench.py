@@ -74,6 +74,10 @@ def main(argv=None) -> int:
     from pytorch_distributed_training_amd.engine import Engine, EngineConfig
     from pytorch_distributed_training_amd.nn import functional as pF
 
+    # N = 1 times the SAME path as N > 1: a size-1 RCCL communicator makes the reducer run flatten -> event fence ->
+    # ncclAllReduce on the communicator's stream -> completion events per bucket, instead of skipping the collective
+    # (the driver's scaling efficiency divides by this number).  PDT_FORCE_COMM=0 restores the communicator-less step.
+    os.environ.setdefault("PDT_FORCE_COMM", "1")
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus and world_env > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
@@ -160,7 +164,10 @@ def main(argv=None) -> int:
                 "backend": env.backend, "baseline_images_per_sec": round(base, 1),
                 "library_fallbacks": dict(pF.fallback_counts), "final_loss": final_loss,
                 "hip_graph": bool(engine._graph is not None), "batch_model": batch_model, "bucket_autotune": engine.net.bucket_autotune,
-                "priming_steps": priming, "sync_bn_comm": engine.sync_bn_comm, "grad_dtype": args.grad_dtype,
+                "priming_steps": priming,
+                # True: every bucket went through ncclAllReduce on the own communicator (also at N = 1)
+                "native_comm": getattr(engine.net.reducer, "rccl", None) is not None,
+                "sync_bn_comm": engine.sync_bn_comm, "grad_dtype": args.grad_dtype,
             },
         }
         sys.stdout.flush()

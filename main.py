@@ -74,7 +74,8 @@ def get_parser() -> argparse.ArgumentParser:
     p.add_argument("--seed", default=None, type=int)
     p.add_argument("--graph", dest="graph", action="store_const", const="on", default="auto",
                    help="capture forward+backward+optimizer of the steady-state step in one hipGraph (default: auto "
-                        "= on for GPU runs on launch-bound images of at most 64x64, off otherwise)")
+                        "= on for single-process GPU runs on launch-bound images of at most 64x64, off otherwise; "
+                        "--graph forces it at any world size)")
     p.add_argument("--no_graph", dest="graph", action="store_const", const="off", help="never capture a hipGraph")
     p.add_argument("--eval", action="store_true", help="run the top-1 evaluation after training (main.py:119-130)")
     p.add_argument("--summary_json", default=None, type=str)
@@ -109,10 +110,12 @@ def main(argv=None) -> int:
     log = metrics.ThroughputLog(job_id, batch_size, global_rank, world_size, args.log_dir)
     timer = metrics.StepTimer()
 
-    # CIFAR-shaped steps are ~550 kernels of a few microseconds: launch-bound, 1.7x faster replayed from a hipGraph
-    # (multi-rank capture: the step then contains the bucket all-reduces on the communicator's stream; a captured
-    # step with ncclAllReduce replays bit-identically, tests/test_gpu.py::test_hip_graph_with_rccl_allreduce_...)
-    use_graph = args.graph == "on" or (args.graph == "auto" and env.device.type == "cuda"
+    # CIFAR-shaped steps are ~550 kernels of a few microseconds: launch-bound, 1.7x faster replayed from a hipGraph.
+    # `auto` captures only in single-process runs: a captured multi-rank step (bucket all-reduces on the
+    # communicator's stream + BN kernels that wait on peers' mailboxes inside the graph) has only been rehearsed
+    # with a size-1 communicator and with two processes on ONE GPU, never on two GPUs, so it stays opt-in
+    # (`--graph`) until a node has run it; the eager W > 1 step goes through the fused C++ nodes instead.
+    use_graph = args.graph == "on" or (args.graph == "auto" and env.device.type == "cuda" and world_size == 1
                                        and max(trainset.sample_shape[1:]) <= 64)
     with profiling.make_profiler(args.profile, job_id) as prof:
         engine = Engine(EngineConfig(

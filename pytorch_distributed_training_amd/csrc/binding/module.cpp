@@ -72,6 +72,9 @@ PYBIND11_MODULE(_C, m) {
         .def("timed_out", &pdt::IpcAllReduce::timed_out)
         .def("clear_error", &pdt::IpcAllReduce::clear_error)
         .def("set_timeout", &pdt::IpcAllReduce::set_timeout)
+        .def("close_peers", &pdt::IpcAllReduce::close_peers, py::call_guard<py::gil_scoped_release>())
+        .def("close", &pdt::IpcAllReduce::close, py::call_guard<py::gil_scoped_release>())
+        .def_property_readonly("closed", &pdt::IpcAllReduce::closed)
         // in-place sum over the ranks of a contiguous fp32 GPU tensor, one kernel on the current stream
         .def("all_reduce_", [](pdt::IpcAllReduce& c, at::Tensor t) {
             TORCH_CHECK(t.is_cuda() && t.is_contiguous() && t.scalar_type() == at::kFloat,

@@ -1425,15 +1425,38 @@ Tensor linear_wgrad(const Tensor& dy, const Tensor& x) {
     TORCH_CHECK(dy.is_contiguous() && x.is_contiguous(), "linear_wgrad: contiguous operands expected");
     const long M = x.size(0), K = x.size(1), N = dy.size(1);
     TORCH_CHECK(dy.size(0) == M, "linear_wgrad: row count mismatch");
-    TORCH_CHECK(M < (1L << 31) && M * K * 2 < (1L << 32) && M * N * 2 < (1L << 32), "linear_wgrad: operand too large");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     if (M == 0) return at::zeros({N, K}, x.options().dtype(at::kFloat));
-    WgradGeom g{(int)M, 1, 1, (int)K, 1, 1, (int)N, 1, 1, 1, 0, 1};
-    g.splits = conv_wgrad_splits(g);
+    // k_conv_wgrad masks ragged channel tiles with the offset kOOB = 2^31 on a descriptor over the whole operand:
+    // that offset is out of range (reads as zero) only while the operand a launch sees is smaller than 2 GiB
+    // (common.h).  Longer token axes (ViT at a batch sized for 288 GB) go in equal row chunks, each a group of
+    // split-K rows of one slab, like the batch chunks of conv2d_wgrad.
+    const long window = g_window_bytes;
+    const long row_bytes = std::max(K, N) * 2;
+    TORCH_CHECK(row_bytes <= window, "linear_wgrad: one row exceeds the activation window");
+    const long max_rows = std::max(1L, window / row_bytes);
+    const long nchunks = (M + max_rows - 1) / max_rows;
+    long per = (M + nchunks - 1) / nchunks;
+    if (nchunks > 1) per = std::min(max_rows, (per + 255) / 256 * 256);
+    std::vector<WgradGeom> geoms;
+    long rows = 0;
+    for (long m0 = 0; m0 < M; m0 += per) {
+        WgradGeom g{(int)std::min(per, M - m0), 1, 1, (int)K, 1, 1, (int)N, 1, 1, 1, 0, 1};
+        g.splits = conv_wgrad_splits(g);
+        if (nchunks > 1) g.splits = std::max<int>(1, (int)((g.splits + nchunks - 1) / nchunks));
+        geoms.push_back(g);
+        rows += g.splits;
+    }
     const long wsize = N * K;
-    Tensor slab = at::empty({g.splits, wsize}, x.options().dtype(at::kFloat));
-    launch_conv_wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr<float>(), g, cur_stream(x));
-    Tensor flat = g.splits == 1 ? slab.view({wsize}) : reduce_slab(slab, g.splits, wsize);
+    Tensor slab = at::empty({rows, wsize}, x.options().dtype(at::kFloat));
+    long row = 0, ci = 0;
+    for (long m0 = 0; m0 < M; m0 += per, ++ci) {
+        launch_conv_wgrad(static_cast<const char*>(dy.data_ptr()) + m0 * N * 2,
+                          static_cast<const char*>(x.data_ptr()) + m0 * K * 2, slab.data_ptr<float>() + row * wsize,
+                          geoms[ci], cur_stream(x));
+        row += geoms[ci].splits;
+    }
+    Tensor flat = rows == 1 ? slab.view({wsize}) : reduce_slab(slab, (int)rows, wsize);
     return flat.view({N, K});
 }
 

@@ -37,9 +37,10 @@ IpcAllReduce::IpcAllReduce(int rank, int world, int device, int cap_elems, doubl
     PDT_HIP(hipMemset(base, 0, bytes_));
     for (auto& m : mb_.mail) m = nullptr;
     mb_.mail[rank] = static_cast<uint64_t*>(base);
-    PDT_HIP(hipMalloc(reinterpret_cast<void**>(&mb_.seq), 2 * sizeof(uint32_t)));
-    PDT_HIP(hipMemset(mb_.seq, 0, 2 * sizeof(uint32_t)));
+    PDT_HIP(hipMalloc(reinterpret_cast<void**>(&mb_.seq), 4 * sizeof(uint32_t)));
+    PDT_HIP(hipMemset(mb_.seq, 0, 4 * sizeof(uint32_t)));
     mb_.done = mb_.seq + 1;
+    mb_.dead = mb_.seq + 2;
     void* hs = nullptr;
     PDT_HIP(hipHostMalloc(&hs, sizeof(uint32_t), hipHostMallocMapped));
     host_status_ = static_cast<volatile uint32_t*>(hs);
@@ -52,13 +53,30 @@ IpcAllReduce::IpcAllReduce(int rank, int world, int device, int cap_elems, doubl
     ready_ = world == 1;
 }
 
-IpcAllReduce::~IpcAllReduce() {
+IpcAllReduce::~IpcAllReduce() { close(); }
+
+void IpcAllReduce::close_peers() {
+    if (closed_) return;
+    ready_ = mb_.world == 1;
     (void)hipSetDevice(device_);
-    (void)hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();  // no kernel of this process still stores into a peer's mailbox or polls ours
     for (void* p : opened_) (void)hipIpcCloseMemHandle(p);
+    opened_.clear();
+    for (int p = 0; p < kIpcMaxRanks; ++p)
+        if (p != mb_.rank) mb_.mail[p] = nullptr;
+}
+
+void IpcAllReduce::close() {
+    if (closed_) return;
+    close_peers();
+    closed_ = true;
+    ready_ = false;
     if (mb_.mail[mb_.rank]) (void)hipFree(mb_.mail[mb_.rank]);
     if (mb_.seq) (void)hipFree(mb_.seq);
     if (host_status_) (void)hipHostFree(const_cast<uint32_t*>(host_status_));
+    for (auto& m : mb_.mail) m = nullptr;
+    mb_.seq = mb_.done = mb_.dead = nullptr;
+    host_status_ = nullptr;
 }
 
 std::string IpcAllReduce::handle() const {
@@ -83,10 +101,15 @@ void IpcAllReduce::open_peers(const std::vector<std::string>& h) {
 }
 
 void IpcAllReduce::clear_error() {
+    if (closed_) return;
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    if (mb_.dead) (void)hipMemset(mb_.dead, 0, sizeof(uint32_t));
     if (host_status_) *host_status_ = 0;
 }
 
 const IpcMailboxes& IpcAllReduce::mailboxes_for(int64_t n) {
+    TORCH_CHECK(!closed_, "IpcAllReduce: closed");
     TORCH_CHECK(ready_, "IpcAllReduce: open_peers() has not run");
     TORCH_CHECK(n >= 0 && n <= mb_.cap, "IpcAllReduce: ", n, " elements exceed the mailbox capacity ", mb_.cap);
     TORCH_CHECK(!timed_out(), "IpcAllReduce: an earlier exchange ran out of time waiting for a peer");
@@ -94,6 +117,7 @@ const IpcMailboxes& IpcAllReduce::mailboxes_for(int64_t n) {
 }
 
 void IpcAllReduce::all_reduce(float* data, int64_t n, hipStream_t s) {
+    TORCH_CHECK(!closed_, "IpcAllReduce: closed");
     TORCH_CHECK(ready_, "IpcAllReduce: open_peers() has not run");
     TORCH_CHECK(n >= 0 && n <= mb_.cap, "IpcAllReduce: ", n, " elements exceed the mailbox capacity ", mb_.cap);
     TORCH_CHECK(!timed_out(), "IpcAllReduce: an earlier all-reduce ran out of time waiting for a peer");

@@ -37,6 +37,8 @@ struct IpcMailboxes {
     uint32_t* seq;            // device word: sequence number of the last finished operation
     uint32_t* done;           // device word: blocks of the running multi-block operation that have finished
     uint32_t* status;         // host-pinned word: set to 1 by a wait that ran out of time
+    uint32_t* dead;           // device copy of `status`: later kernels (a replayed hipGraph has up to 106 more
+                              // exchanges queued behind the one that failed) read it and do not wait again
     long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
 };
 
@@ -57,6 +59,13 @@ class IpcAllReduce {
     int world_size() const { return mb_.world; }
     bool timed_out() const { return host_status_ != nullptr && *host_status_ != 0; }
     void clear_error();
+    // ordered teardown: device synchronised, peer mappings closed, mailbox freed; idempotent, the object is
+    // unusable afterwards (dist.shutdown calls it before the process group goes away)
+    // (an exporter must not free memory a peer still has mapped: a job closes in two phases with a barrier
+    // between them, `close_peers()` on every rank, then `close()`; parallel/ipc.py does that)
+    void close_peers();
+    void close();
+    bool closed() const { return closed_; }
     void set_timeout(double seconds) { mb_.timeout_ticks = (long long)(seconds * 100e6); }
     void all_reduce(float* data, int64_t n, hipStream_t s);
     // for kernels that do the exchange themselves (ipc_device.h): the mailboxes, after the same checks as above
@@ -66,6 +75,7 @@ class IpcAllReduce {
     int device_;
     size_t bytes_ = 0;
     bool ready_ = false;
+    bool closed_ = false;
     long calls_ = 0;
     IpcMailboxes mb_{};
     volatile uint32_t* host_status_ = nullptr;

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(kIpcThreads) void k_ipc_allreduce(float* __restrict
     for (int i = threadIdx.x; i < n; i += kIpcThreads) ipc_push(mb, seq, i, data[i]);
     // gather from the local mailbox, senders in rank order (identical rounding on every rank)
     const long long t0 = wall_clock64();
-    bool late = false;
+    bool late = ipc_dead(mb);
     for (int i = threadIdx.x; i < n; i += kIpcThreads) {
         float acc = 0.f;
         for (int s = 0; s < mb.world; ++s) acc += ipc_wait(mb, seq, s, i, &late, t0);

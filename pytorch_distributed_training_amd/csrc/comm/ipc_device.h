@@ -5,6 +5,7 @@
 //
 //   const uint32_t seq = ipc_begin(mb);                     every thread of every block (reads the device word)
 //   ipc_push(mb, seq, i, value);                            element i of this rank's message -> every mailbox
+//   bool late = ipc_dead(mb);                               (an earlier exchange timed out: do not wait again)
 //   v = ipc_wait(mb, seq, sender, i, &late, t0);            polls the OWN mailbox (local memory)
 //   ipc_end(mb, seq, late);                                 every thread, at the end of the kernel
 //
@@ -29,6 +30,12 @@ __device__ __forceinline__ uint32_t ipc_begin(const IpcMailboxes& mb) {
     uint32_t seq = __hip_atomic_load(mb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (seq == 0u) seq = 2u;  // 0 is the flag of a never-written word; keep the parity alternating across the wrap
     return seq;
+}
+
+// true once an earlier exchange of this job ran out of time: start with `bool late = ipc_dead(mb);` so that the
+// kernels queued behind the failed one (the rest of a replayed hipGraph) do not each wait the time limit again
+__device__ __forceinline__ bool ipc_dead(const IpcMailboxes& mb) {
+    return __hip_atomic_load(mb.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 }
 
 // own mailbox last, peers starting from rank+1 so the ranks do not all hit the same target at once
@@ -68,7 +75,10 @@ __device__ __forceinline__ float ipc_wait(const IpcMailboxes& mb, uint32_t seq, 
 
 // every thread of the grid calls this once, after its last wait (contains a block barrier)
 __device__ __forceinline__ void ipc_end(const IpcMailboxes& mb, uint32_t seq, bool late) {
-    if (late) __hip_atomic_store(mb.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (late) {
+        __hip_atomic_store(mb.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(mb.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
         const uint32_t blocks = gridDim.x * gridDim.y * gridDim.z;

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize(const float* __restric
                                                           float* __restrict__ count_out) {
     const bool exchange = mb.world > 1 && mean != nullptr;
     const uint32_t seq = exchange ? ipc_begin(mb) : 0u;
-    bool late = false;
+    bool late = exchange && ipc_dead(mb);
     // The partial rows are summed in DOUBLE and the variance is formed in double: E[x^2] - E[x]^2 cancels
     // catastrophically in fp32 once |mean| >> std (a million fp32 additions lose ~1e-6 of sum(x^2), which is
     // (mean/std)^2 * 1e-6 of the variance).  With double here the only fp32 rounding left is inside one tile's
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_coef(const float* __restric
     const int c = blockIdx.x * 32 + cl;
     const bool exchange = mb.world > 1;
     const uint32_t seq = exchange ? ipc_begin(mb) : 0u;
-    bool late = false;
+    bool late = exchange && ipc_dead(mb);
     float sa = 0.f, sb = 0.f;
     if (c < C)
         for (int p = pl; p < nps; p += 8) {
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_elemt(const bf16* __restric
     // lane of EVERY block polls the mailbox for its 8 channels and hands the totals to the block through LDS
     const bool exchange = mb.world > 1 && coef == nullptr;
     const uint32_t seq = exchange ? ipc_begin(mb) : 0u;
-    bool late = false;
+    bool late = exchange && ipc_dead(mb);
     if (coef != nullptr) {  // big tensors: k_bn_bwd_coef made the table, a block only streams its one chunk
         ld8f(coef + m.cg * 8, k1);
         ld8f(coef + C + m.cg * 8, k2);

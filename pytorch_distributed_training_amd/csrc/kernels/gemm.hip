@@ -45,7 +45,16 @@ constexpr int STAGE_BYTES = 4 * HALF_BYTES;    // A-lo, A-hi, B-lo, B-hi
 // an output tile (128 rows) in "extra" plus the stage buffer that does NOT receive the next tile's first K-tile.
 constexpr int EXTRA_OFF = STAGE_BYTES, STAGE1_OFF = STAGE_BYTES + 32768;
 constexpr int LDS_BYTES = STAGE1_OFF + STAGE_BYTES;  // 163840
-constexpr int OPITCH = BN * 2 + 16;                  // staged output row pitch (bytes)
+// Staged output rows are 512 B with NO padding; bank conflicts are avoided by an XOR swizzle instead.  A padded
+// pitch must stay a multiple of 16 B for the ds_read_b128 row pass, i.e. a multiple of 4 banks: with 528 B the
+// 16 lanes of a ds_write_b64 group (16 consecutive rows, one 8-B column granule) fell on banks 4r, 4r+1 (mod 32):
+// rows r and r+8 collided and half the banks idled: 2-way conflicts on all 32 staging stores of a wave, 18-19 % of
+// the kernel's LDS cycles on the short-K convolution launches (profiles/r2_pmc_b1024_summary.md).  Swizzle: the
+// 16-B chunk index is XORed with (row & 7) and the 8-B half inside the chunk with bit 3 of the row, so the 16 rows
+// of a store group hit 16 different 8-B bank pairs, and the 16 lanes of a ds_read_b128 group (one row, 16 chunks
+// that are distinct mod 16) stay conflict-free.  The reader's row has bit 3 == bit 3 of (tid >> 5): wave-uniform,
+// waves 4-7 swap the two halves of what they read.
+constexpr int OPITCH = BN * 2;                       // staged output row pitch (bytes)
 static_assert(128 * OPITCH <= STAGE_BYTES + 32768, "half-tile staging fits");
 
 __device__ __forceinline__ float gelu_erf_part(float u, float* pdf_out) {
@@ -332,7 +341,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                     for (int i = 0; i < 8; ++i) {
                         const f32x4_t v = acc[i][j] + bv;
                         const bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        *reinterpret_cast<bf16x4*>(Os + (i * 16 + l15) * OPITCH + (wcol + j * 16) * 2) = pk;
+                        *reinterpret_cast<bf16x4*>(Os + (i * 16 + l15) * OPITCH + (((wc * 8 + j * 2 + (lq >> 1)) ^ (l15 & 7)) << 4) +
+                                                   (((lq & 1) ^ (l15 >> 3)) << 3)) = pk;
                     }
                 }
             }
@@ -372,7 +382,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
 #pragma unroll
                 for (int p = 0; p < PB; ++p) {
                     const int lrow = (pb + p) * 16 + orow;
-                    bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + lrow * OPITCH + och * 16);
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + lrow * OPITCH + ((och ^ (orow & 7)) << 4));
+                    if (wave >= 4) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);  // rows with bit 3 set
                     if (ACT)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, coff[p], 0, kAuxStream);
                     if (ACT) {

@@ -8,7 +8,9 @@
 
 #include <dlfcn.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <ctime>
 
 #include "../binding/binding.h"
 
@@ -39,6 +41,19 @@ struct Roctx {
 Roctx& roctx() {
     static Roctx r;
     return r;
+}
+// PDT_TRACE_COLL=1: one stderr line per bucket launch / wait (which collectives are outstanding when a job stalls)
+bool trace_coll() {
+    static const bool on = [] {
+        const char* e = std::getenv("PDT_TRACE_COLL");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+double mono_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 struct RoctxRange {
     bool on;
@@ -256,7 +271,9 @@ void Reducer::launch(Bucket& b) {
             std::vector<at::Tensor> ts{b.flat};
             c10d::AllreduceOptions opts;
             opts.reduceOp = c10d::ReduceOp::SUM;
+            if (trace_coll()) fprintf(stderr, "[coll r%d %.4f] bucket%zu it%ld issue\n", pg_->getRank(), mono_s(), bidx, (long)iteration_);
             b.work = pg_->allreduce(ts, opts);
+            if (trace_coll()) fprintf(stderr, "[coll r%d %.4f] bucket%zu it%ld issued\n", pg_->getRank(), mono_s(), bidx, (long)iteration_);
         }
     }
     b.launched = true;
@@ -306,8 +323,11 @@ void Reducer::finalize() {
         } else {
             for (auto& b : buckets_)
                 if (b.work) {
+                    const size_t bidx = (size_t)(&b - buckets_.data());
+                    if (trace_coll()) fprintf(stderr, "[coll r%d %.4f] bucket%zu it%ld wait\n", pg_->getRank(), mono_s(), bidx, (long)iteration_);
                     b.work->wait();
                     b.work.reset();
+                    if (trace_coll()) fprintf(stderr, "[coll r%d %.4f] bucket%zu it%ld done\n", pg_->getRank(), mono_s(), bidx, (long)iteration_);
                 }
         }
     }

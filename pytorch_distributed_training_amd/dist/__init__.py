@@ -155,7 +155,8 @@ def shutdown(engine=None, timeout_s: float = 60.0) -> None:
     1. barrier: every rank is past its last collective;
     2. ``engine.close()``: reducer hooks off, device synchronised, the native communicator closed
        (watchdog thread joined -> communicator stream drained -> ``ncclCommDestroy``);
-    3. any other native communicator of this process closed the same way;
+    3. any other native communicator of this process closed the same way, then the IPC mailboxes
+       (``parallel.ipc.close_all``: peers' mappings closed, own memory freed);
     4. ``destroy_process_group()`` (c10d's own communicators and the store).
 
     If a peer died and a step blocks, the timer ends this process with exit code 3 after ``timeout_s`` instead of
@@ -183,12 +184,9 @@ def shutdown(engine=None, timeout_s: float = 60.0) -> None:
             close_all_comms()
         except ImportError:
             pass
-        try:
-            from ..parallel import ipc
+        from ..parallel import ipc
 
-            ipc.close_all()
-        except (ImportError, AttributeError):
-            pass
+        ipc.close_all()  # hipIpc mappings of the peers' mailboxes closed, own mailboxes freed
         destroy_process_group()
     finally:
         done.set()

@@ -58,6 +58,38 @@ def compute_dtype(cfg: EngineConfig, device: torch.device) -> torch.dtype:
     return {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[cfg.dtype]
 
 
+class CapturedStep:
+    """One training step captured in a hipGraph: static input buffers, the graph, its static output.
+
+    ``ipc`` is the SyncBN mailbox set (``parallel.ipc.IpcSmallAllReduce``) whose exchanges are INSIDE the captured
+    kernels, or None.  Eager launches check the mailboxes' status word on the host at every launch
+    (``IpcAllReduce::mailboxes_for``); a replayed graph launches nothing through that code, so ``replay`` reads the
+    word itself, before it enqueues (what the previous replay left; no device sync): a peer that was late inside a
+    replay fed this rank's BN kernels stale statistics, and the job must stop instead of training on them.  The
+    kernels queued behind the exchange that timed out see the device-side copy of the word and do not wait again
+    (``ipc_dead`` in ``csrc/comm/ipc_device.h``), so the host gets here one time limit after the peer went missing,
+    not 106 of them."""
+
+    def __init__(self, fn, inputs, stream: torch.cuda.Stream, ipc=None):
+        self.inputs = tuple(inputs)
+        self.ipc = ipc
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=stream):
+            self.output = fn(*self.inputs)
+
+    def check_peers(self, when: str = "the previous replayed step") -> None:
+        if self.ipc is not None and self.ipc.timed_out():
+            raise RuntimeError(f"SyncBatchNorm exchange: a peer did not arrive within {self.ipc.timeout_s:.0f} s in "
+                               f"{when} (IPC mailbox status word set); its statistics are not to be trusted")
+
+    def replay(self, *inputs):
+        self.check_peers()
+        for dst, src in zip(self.inputs, inputs):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.output
+
+
 class Engine:
     def __init__(self, cfg: EngineConfig, device: torch.device | None = None):
         env = pdist.env()
@@ -75,6 +107,7 @@ class Engine:
         self.optimizer = build_optimizer(cfg.optimizer, net.parameters(), cfg.lr, cfg.momentum, cfg.weight_decay)
         net = net.to(self.device)
         self.sync_bn_comm = None
+        self._ipc = None  # the SyncBN mailboxes (parallel/ipc.py) when the in-kernel exchange is in use
         if cfg.sync_bn:
             sync_group = pnn.make_sync_bn_group()
             net = pnn.convert_sync_batchnorm(net, process_group=sync_group)
@@ -82,7 +115,7 @@ class Engine:
                 # decide the statistics all-reduce path now (collective), not inside the first forward
                 from .parallel.ipc import small_all_reduce_path
 
-                self.sync_bn_comm = small_all_reduce_path(sync_group, self.device)[1]
+                self._ipc, self.sync_bn_comm = small_all_reduce_path(sync_group, self.device)
         self.dtype = compute_dtype(cfg, self.device)
         dev_ids = [self.device.index] if self.device.type == "cuda" else None
         self.net = DistributedDataParallel(
@@ -95,7 +128,7 @@ class Engine:
         if profiling.roctx_enabled():
             self.net.reducer.set_roctx(True)
         self.net.train()
-        self._graph = None          # (CUDAGraph, static_imgs, static_labels, static_loss)
+        self._graph = None          # CapturedStep
         self._graph_key = None
         self._eager_steps = 0
         self._graph_failed = None
@@ -133,9 +166,11 @@ class Engine:
 
     def close(self) -> None:
         """Ordered teardown of the replica (call before ``dist.shutdown``)."""
-        self._graph = None
+        g, self._graph = self._graph, None
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
+        if g is not None:
+            g.check_peers("the last replayed step")
         self.net.close()
 
     def _graph_step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
@@ -143,18 +178,14 @@ class Engine:
         steps: reducer rebuild, lazy optimizer state, kernel attributes; and the short last batch of an epoch)."""
         key = (tuple(imgs.shape), imgs.dtype, tuple(labels.shape), labels.dtype)
         if self._graph is not None and key == self._graph_key:
-            g, s_imgs, s_labels, s_loss = self._graph
-            s_imgs.copy_(imgs, non_blocking=True)
-            s_labels.copy_(labels, non_blocking=True)
-            g.replay()
-            return s_loss
+            return self._graph.replay(imgs, labels)
         # capture only a steady-state step: past the warm-up, gradients synchronised, and the reducer's one-off bucket
         # rebuild (start of iteration 2) behind us, so the captured launch sequence is the one every later step has
         if (self._graph is None and self._eager_steps >= self.cfg.graph_warmup and self.net._require_sync
                 and getattr(self.net.reducer, "rebuilt", True)):
             try:
                 self._capture(imgs, labels, key)
-                return self._graph[3]
+                return self._graph.output
             except Exception as e:  # leave the job running on the eager path and say why
                 self._graph_failed = repr(e)
                 self._graph = None
@@ -176,12 +207,10 @@ class Engine:
                 p.grad = None
             if hasattr(self.net.reducer, "rehook"):
                 self.net.reducer.rehook()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=self._capture_stream):
-            s_loss = self._eager_step(s_imgs, s_labels)
-        self._graph, self._graph_key = (g, s_imgs, s_labels, s_loss), key
+        self._graph = CapturedStep(self._eager_step, (s_imgs, s_labels), self._capture_stream, self._ipc)
+        self._graph_key = key
         # the capture pass enqueued nothing: run the step it recorded for this batch
-        g.replay()
+        self._graph.graph.replay()
 
     def _eager_step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         self._eager_steps += 1

@@ -46,34 +46,49 @@ def _parse_nnodes(value: str) -> int:
 
 
 def _gpu_count() -> int:
-    """Visible GPUs WITHOUT touching the HIP runtime in this process: the launcher forks + execs every worker, and
+    """Usable GPUs WITHOUT touching the HIP runtime in this process: the launcher forks + execs every worker, and
     an exec out of a process that has initialised the GPU is refused on some pools (and leaks /dev/kfd state into
-    the children).  Order: the visibility variables, then the KFD topology in sysfs, then a short-lived child."""
+    the children).  Order: the visibility variables; the KFD topology in sysfs, counting only the nodes whose DRM
+    render device this process can open (sysfs lists every GPU of the HOST, a container or cgroup may expose only
+    some of them: their /dev/dri/renderD* nodes are then absent or not accessible); a short-lived child process
+    asking ``torch.cuda.device_count()`` when sysfs does not say (no render minor recorded)."""
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
             return len([t for t in v.split(",") if t.strip() != ""])
-    topo = "/sys/class/kfd/kfd/topology/nodes"
-    try:
-        n = 0
-        for node in os.listdir(topo):
-            try:
-                with open(os.path.join(topo, node, "properties")) as fh:
-                    props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
-                if int(props.get("simd_count", "0")) > 0:  # CPU nodes report 0 SIMDs
-                    n += 1
-            except (OSError, ValueError):
-                continue
-        if n > 0:
-            return n
-    except OSError:
-        pass
+    n = _gpu_count_sysfs()
+    if n is not None:
+        return n
     try:
         out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300)
         return int(out.stdout.strip().splitlines()[-1])
     except Exception:
         return 0
+
+
+def _gpu_count_sysfs(topo: str = "/sys/class/kfd/kfd/topology/nodes", dri: str = "/dev/dri"):
+    """GPU nodes of the KFD topology whose render device is accessible; None when the topology cannot answer
+    (not readable, or a GPU node without a ``drm_render_minor``)."""
+    try:
+        nodes = os.listdir(topo)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(topo, node, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) <= 0:  # CPU nodes report 0 SIMDs
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+        except (OSError, ValueError):
+            continue
+        if minor < 0:
+            return None
+        if os.access(os.path.join(dri, f"renderD{minor}"), os.R_OK | os.W_OK):
+            n += 1
+    return n
 
 
 def determine_local_world_size(nproc_per_node: str) -> int:

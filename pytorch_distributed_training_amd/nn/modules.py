@@ -11,6 +11,8 @@
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as tdist
 import torch.nn as tnn
@@ -111,6 +113,8 @@ def make_sync_bn_group():
     """A dedicated communicator for SyncBN so its tiny latency-bound all-reduces
     never queue behind a gradient bucket on the same RCCL stream."""
     if not (tdist.is_available() and tdist.is_initialized()) or tdist.get_world_size() == 1:
+        return None
+    if os.environ.get("PDT_SYNCBN_GROUP", "own").lower() == "default":  # diagnostic: share the WORLD group
         return None
     return tdist.new_group(ranks=list(range(tdist.get_world_size())))
 

@@ -86,11 +86,14 @@ class DistributedDataParallel(tnn.Module):
         if compute_dtype is not None and compute_dtype != torch.float32:
             self.param_arena.attach_lowp(compute_dtype)
 
+        from ..nn.modules import SyncBatchNorm
+
+        bns = [m for m in module.modules() if isinstance(m, tnn.modules.batchnorm._BatchNorm)]
+        # replicas compute identical running statistics only when EVERY BN is a SyncBN (from the module scan, not
+        # from the argument: plain BN with broadcast_buffers=False legitimately keeps per-rank statistics)
+        self._all_sync_bn = all(isinstance(m, (SyncBatchNorm, tnn.SyncBatchNorm)) for m in bns)
         if broadcast_buffers == "auto":
-            bns = [m for m in module.modules() if isinstance(m, tnn.modules.batchnorm._BatchNorm)]
-            from ..nn.modules import SyncBatchNorm
-            broadcast_buffers = any(not isinstance(m, (SyncBatchNorm, tnn.SyncBatchNorm)) for m in bns)
-        self._all_sync_bn = not bool(broadcast_buffers)  # replicas then compute identical running statistics
+            broadcast_buffers = not self._all_sync_bn
         self.broadcast_buffers = bool(broadcast_buffers) and self.world_size > 1
 
         self.bucket_autotune = None

@@ -97,6 +97,23 @@ class IpcSmallAllReduce:
     def timed_out(self) -> bool:
         return self.native is not None and self.native.timed_out()
 
+    def close(self, collective: bool = True) -> None:
+        """Two phases: device synchronised and the peers' mappings closed; a barrier over the group (an exporter
+        must not free memory that a peer still has mapped); own mailbox freed.  Collective unless
+        ``collective=False`` (a rank that tears down alone after its peers died: no barrier).  Call it only once
+        every rank is past its last exchange (``dist.shutdown`` does, behind its own barrier): a peer's kernel
+        that still stores into this mailbox would fault."""
+        if self.native is None:
+            return
+        self.native.close_peers()
+        if collective and self.world > 1:
+            if tdist.get_backend(self.group) == "nccl":
+                tdist.barrier(group=self.group, device_ids=[self.device.index or 0])
+            else:
+                tdist.barrier(group=self.group)
+        self.native.close()
+        self.native = None
+
     def _group_all_reduce(self, t: torch.Tensor) -> None:
         if t.is_cuda and tdist.get_backend(self.group) == "gloo":  # (tests: a CPU group driving GPU mailboxes)
             c = t.cpu()
@@ -209,11 +226,22 @@ def small_all_reduce_path(group, device):
     return _paths[key]
 
 
+_TRACE = os.environ.get("PDT_TRACE_COLL", "0") == "1"  # one stderr line per small all-reduce (issue / done)
+_trace_n = 0
+
+
 def small_all_reduce(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM of a small fp32 vector over ``group`` on the current stream."""
+    global _trace_n
     ipc, _ = small_all_reduce_path(group, t.device)
     if ipc is not None and t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= ipc.capacity:
         ipc.all_reduce_(t)
+    elif _TRACE:
+        _trace_n += 1
+        r = tdist.get_rank()
+        print(f"[coll r{r} {time.monotonic():.4f}] small#{_trace_n} n={t.numel()} issue", file=sys.stderr, flush=True)
+        tdist.all_reduce(t, group=group)
+        print(f"[coll r{r} {time.monotonic():.4f}] small#{_trace_n} done", file=sys.stderr, flush=True)
     else:
         tdist.all_reduce(t, group=group)
     return t
@@ -221,3 +249,16 @@ def small_all_reduce(t: torch.Tensor, group=None) -> torch.Tensor:
 
 def reset_paths() -> None:
     _paths.clear()
+
+
+def close_all() -> int:
+    """Ordered teardown of every mailbox set this process created: ``close()`` each (synchronise, unmap the peers,
+    free), then forget the per-group decisions.  -> number of IPC paths closed.  Part of ``dist.shutdown``, between
+    the native communicators and ``destroy_process_group`` (every rank is behind the shutdown barrier by then)."""
+    n = 0
+    for ipc, _ in list(_paths.values()):
+        if ipc is not None:
+            ipc.close()
+            n += 1
+    _paths.clear()
+    return n

@@ -207,6 +207,51 @@ def main() -> int:
         cos = min(cos, float(torch.dot(g2.flatten(), g1) / (g2.norm() * g1.norm() + 1e-12)))
     out["dual_dw_cos"] = cos
 
+    # 4e. a step captured in a hipGraph whose BN kernels do the exchange themselves (engine.CapturedStep): replays equal
+    # the eager step on both ranks; then rank 1 stops replaying.  Rank 0's next replay runs out of time in its FIRST
+    # exchange, the exchanges queued behind it inside the graph see the device-side flag and do not wait again, and
+    # the replay after that raises on the host instead of returning a loss computed from stale statistics.
+    from pytorch_distributed_training_amd.engine import CapturedStep
+
+    path_ipc = pipc.small_all_reduce_path(None, dev)[0]
+    limit_s = 2.0
+    path_ipc.native.set_timeout(limit_s)  # (the time limit travels by value inside the captured kernel arguments)
+    path_ipc.timeout_s = limit_s
+    bn_g = pnn.SyncBatchNorm(c).to(dev)
+    xg = full[rank * per:(rank + 1) * per].clone()
+
+    def bn_step(xin):
+        xi = xin.detach().clone().requires_grad_(True)
+        o = bn_g(xi, relu=True).float()
+        loss = (o * o).mean()
+        loss.backward()
+        return loss.detach()
+
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        eager = [float(bn_step(xg)) for _ in range(2)]
+    torch.cuda.synchronize()
+    tdist.barrier()
+    cs = CapturedStep(bn_step, (xg.clone(),), side, path_ipc)
+    reps = []
+    for _ in range(3):
+        reps.append(float(cs.replay(xg)))
+    torch.cuda.synchronize()
+    out["captured_losses"] = [eager, reps]
+    tdist.barrier()
+    if rank == 0:
+        t0 = time.perf_counter()
+        cs.replay(xg)          # the peer is absent: forward exchange times out, backward exchange must not wait again
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        try:
+            cs.replay(xg)
+            raised = False
+        except RuntimeError as e:
+            raised = "peer did not arrive" in str(e)
+        out["captured_peer_missing"] = {"elapsed_s": dt, "limit_s": limit_s, "raised": raised}
+    tdist.barrier()
+
     # 5. a peer that never arrives: the kernel gives up after the limit, the flag is raised, the next call refuses
     torch.cuda.synchronize()
     tdist.barrier()
@@ -221,6 +266,11 @@ def main() -> int:
         except RuntimeError:
             out["refused_after_timeout"] = True
     tdist.barrier()
+    # 6. ordered teardown (dist.shutdown's step 3): every path closed in two phases around a barrier, nothing left
+    n_paths = len([1 for v in pipc._paths.values() if v[0] is not None])
+    out["closed_paths"] = [n_paths, pipc.close_all(), len(pipc._paths), path_ipc.native is None]
+    red.close()
+    out["red_closed"] = red.native is None and not red.ok
     print(json.dumps(out), flush=True)
     tdist.destroy_process_group()
     return 0

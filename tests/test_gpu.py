@@ -929,8 +929,16 @@ def test_ipc_small_allreduce_two_processes_on_one_gpu(tmp_path):
         # bottleneck net: 4 downsample blocks, dual BN backward with in-kernel exchange in the SyncBN run only
         assert o["dual_calls"] == [4, 4, True, False], o
         assert o["dual_out_err"] < 0.05 and o["dual_dw_cos"] > 0.9, o
+        # a captured step with the exchange inside its kernels replays to the eager losses on every rank
+        assert o["captured_losses"][1] == pytest.approx([o["captured_losses"][0][-1]] * 3, rel=1e-5), o
+        # ordered teardown: the SyncBN path's mailboxes were there, close_all() closed them and forgot them
+        assert o["closed_paths"][0] >= 1 and o["closed_paths"][1] == o["closed_paths"][0], o
+        assert o["closed_paths"][2] == 0 and o["closed_paths"][3] and o["red_closed"], o
     r0 = [o for o in outs if o["rank"] == 0][0]
     assert r0["timed_out"] and r0["refused_after_timeout"], r0
+    # peer missing inside a replayed graph: ONE time limit (not one per exchange), then the next replay raises
+    pm = r0["captured_peer_missing"]
+    assert pm["raised"] and pm["limit_s"] * 0.9 < pm["elapsed_s"] < pm["limit_s"] * 1.8, pm
     print("ipc all-reduce us/op:", r0["ipc_us"], " gloo-staged group us/op:", r0["group_us"])
     print("us per BN layer (fwd+bwd), 2 ranks on one GPU:", r0["layer_us"])
     # the in-kernel exchange must not cost more than the packed tensor + all-reduce kernel path it replaces
