@@ -35,8 +35,8 @@ GRAD_BYTES = 25_557_032 * 4
 def run_measured(n: int, args) -> dict:
     cmd = [sys.executable, "-m", "pytorch_distributed_training_amd.launch", f"--nproc_per_node={n}",
            "--master_addr=127.0.0.1", f"--master_port={29600 + n}", "--use_env", os.path.join(ROOT, "bench.py"),
-           "--gpus", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch_size",
-           str(args.batch_size)] + (["--sync_bn"] if args.sync_bn else [])
+           "--gpus", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup)] + \
+        (["--batch_size", str(args.batch_size)] if args.batch_size else []) + (["--sync_bn"] if args.sync_bn else [])
     env = dict(os.environ, PYTHONPATH=ROOT)
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)
     if out.returncode != 0:
@@ -74,7 +74,11 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch_size", type=int, default=256)
+    ap.add_argument("--batch_size", type=int, default=None,
+                    help="per-GPU batch; default: bench.py's own default (2560 for ResNet-50 at 224x224), so that the "
+                         "curve is the headline benchmark's")
+    ap.add_argument("--step_ms", type=float, default=None, help="model mode without a log: measured 1-GPU ms/step")
+    ap.add_argument("--md", action="store_true", help="model mode: also print the curves as a markdown table")
     ap.add_argument("--sync_bn", action="store_true")
     ap.add_argument("--syncbn_comm", default="ipc", choices=["ipc", "rccl"],
                     help="modelled path of the SyncBN statistics all-reduce (parallel/ipc.py)")
@@ -88,19 +92,33 @@ def main() -> int:
         cal = json.loads(open(a.calibration).read().strip().splitlines()[-1])
         LINK_GBPS, COLL_LATENCY_US = float(cal["link_GBps"]), float(cal["collective_latency_us"])
         bucket_mb = float(cal.get("bucket_mb", bucket_mb))
-    if a.model_from:
-        line = [l for l in open(a.model_from).read().splitlines() if l.startswith("{")][-1]
-        d = json.loads(line)
-        assert d["n_gpus"] == 1
-        batch = d["config"]["per_gpu_batch"]
-        result = {"source": a.model_from, "link_GBps": LINK_GBPS, "collective_latency_us": COLL_LATENCY_US,
+    if a.model_from or a.step_ms:
+        if a.model_from:
+            line = [l for l in open(a.model_from).read().splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+            assert d["n_gpus"] == 1
+            batch, step_ms = d["config"]["per_gpu_batch"], d["ms_per_step"]
+        else:
+            batch, step_ms = a.batch_size or 2560, a.step_ms
+        result = {"source": a.model_from or f"--step_ms {a.step_ms}", "per_gpu_batch": batch, "sync_bn": a.sync_bn,
+                  "link_GBps": LINK_GBPS, "collective_latency_us": COLL_LATENCY_US,
                   "constants": "calibrated: " + a.calibration if a.calibration else "task-brief defaults (unmeasured)",
-                  "ring": model_curve(d["ms_per_step"], batch, a.sync_bn, bucket_mb, "ring", a.syncbn_comm),
-                  "direct": model_curve(d["ms_per_step"], batch, a.sync_bn, bucket_mb, "direct", a.syncbn_comm)}
+                  "ring": model_curve(step_ms, batch, a.sync_bn, bucket_mb, "ring", a.syncbn_comm),
+                  "direct": model_curve(step_ms, batch, a.sync_bn, bucket_mb, "direct", a.syncbn_comm)}
+        if a.md:
+            print(f"MODELLED (not measured): B={batch}/GPU, sync_bn={a.sync_bn}, {result['constants']}: link "
+                  f"{LINK_GBPS:g} GB/s, {COLL_LATENCY_US:g} us per collective")
+            print("| GPUs | ring all-reduce: img/s | efficiency | two-shot direct: img/s | efficiency | kind |")
+            print("|---|---|---|---|---|---|")
+            for r, dr in zip(result["ring"], result["direct"]):
+                print(f"| {r['n_gpus']} | {r['images_per_sec']:.0f} | {r['efficiency']:.3f} | {dr['images_per_sec']:.0f} | "
+                      f"{dr['efficiency']:.3f} | {r['kind']} |")
     else:
-        import torch
+        # (no HIP call in this parent: it forks the launchers; see launch._gpu_count)
+        sys.path.insert(0, ROOT)
+        from pytorch_distributed_training_amd.launch import _gpu_count
 
-        avail = torch.cuda.device_count()
+        avail = _gpu_count()
         rows, base = [], None
         for n in a.gpus:
             if n > avail:

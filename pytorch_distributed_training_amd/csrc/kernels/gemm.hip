@@ -174,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
     const int nt = TAPS ? a.ntaps * (a.K / BK) : (a.K + BK - 1) / BK;
     // slot: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi; t = K-tile of the current operand state; par = its stage buffer
     auto issue = [&](int hslot, int t, int par) {
+        if (a.debug_nostore & 8) return;  // (timing diagnostics: no operand DMA)
         const uint32_t dst = piece_base + (uint32_t)(stage_off(par) + hslot * HALF_BYTES);
         const bool isB = hslot >= 2;
         const int h = hslot & 1;
@@ -269,12 +270,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                 __builtin_amdgcn_s_barrier();
                 // ---------------- MFMA segment
                 __builtin_amdgcn_s_setprio(1);
+                if (!(a.debug_nostore & 4)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[ks][j], afrag[i],
-                                                                                      acc[mh * 4 + i][j], 0, 0, 0);
+                        for (int j = 0; j < 4; ++j)
+                            acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[ks][j], afrag[i],
+                                                                                          acc[mh * 4 + i][j], 0, 0, 0);
+                } else {
+                    acc[mh * 4][0][0] += (float)afrag[0][0] + (float)bfrag[ks][0][0];  // keep the fragment reads alive
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_s_barrier();
             }
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
         char* Os = smem + (npar == 0 ? EXTRA_OFF : 0);
         const int ncol = on0 + och * 8;
         const bool col_ok = ncol < a.N;  // N % 8 == 0
-        const uint32_t cbytes = a.debug_nostore ? 0u : (uint32_t)((long)orows_m * a.ldc * 2);
+        const uint32_t cbytes = (a.debug_nostore & 1) ? 0u : (uint32_t)((long)orows_m * a.ldc * 2);
         const __amdgpu_buffer_rsrc_t rc = make_rsrc(static_cast<char*>(a.C) + om0 * a.ldc * 2, cbytes);
         const __amdgpu_buffer_rsrc_t rp = make_rsrc(ACT ? static_cast<char*>(a.preact_out) + om0 * a.ldc * 2 : nullptr, ACT ? cbytes : 0u);
         // one optional extra bf16 operand: the residual / gated addend (added) or the GELU input (its derivative
@@ -329,6 +334,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
 
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
+            if (a.debug_nostore & 2) break;  // (timing diagnostics: no staging, no row pass)
             if (wr == hh) {
                 // lane holds, for 16x16 tile (i, j): row i*16 + lane%16, columns j*16 + (lane/16)*4 + 0..3
                 const int wcol = wc * 64 + lq * 4;
@@ -510,8 +516,10 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
     // 32 tiles run together on one XCD: with many tile columns walk bands of 4 tile rows (4 A panels + 8 B panels
     // per K-step instead of 1 + 32)
     a.group_m = a.n_tiles > 12 ? 4 : 1;
-    static const bool nostore = std::getenv("PDT_GEMM_NOSTORE") != nullptr;  // timing diagnostics only
-    a.debug_nostore = nostore ? 1 : 0;
+    // timing diagnostics only (results are wrong): PDT_GEMM_NOSTORE, or PDT_GEMM_DEBUG = bit mask of 1 drop the
+    // output stores, 2 skip the epilogue, 4 skip the MFMAs, 8 skip the operand DMA; re-read at every launch
+    const char* dbg = std::getenv("PDT_GEMM_DEBUG");
+    a.debug_nostore = (std::getenv("PDT_GEMM_NOSTORE") != nullptr ? 1 : 0) | (dbg ? std::atoi(dbg) : 0);
     const int total = a.m_tiles * a.n_tiles;
     static const int cus = [] {
         int dev = 0, n = 256;

@@ -274,7 +274,8 @@ struct GemmArgs {
     int32_t tap[9];  // (dh & 0xff) | (dw & 0xff) << 8 | wslot << 16
     FastDiv div_w, div_hw, div_kt;  // / W, / (H * W), / (K / 64)
     int m_tiles, n_tiles, group_m;  // filled by the launcher
-    int debug_nostore;              // timing diagnostics: the output descriptor gets zero records (stores dropped)
+    int debug_nostore;              // timing diagnostics, bit mask: 1 output stores dropped (zero-size descriptor),
+                                    // 2 epilogue skipped, 4 MFMAs skipped, 8 operand DMA skipped
 };
 // 3x3 / stride 1 / pad 1 with 64 -> 64 channels: weights in registers, input window staged once per tile (conv_win64.hip)
 bool conv_win64_ok(int C, int N, int KH, int KW, int stride, int pad, int H, int W);

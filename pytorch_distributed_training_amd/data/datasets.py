@@ -5,9 +5,11 @@ transform=ToTensor())`` (``/root/reference/main.py:42-51``): 50 000 train /
 10 000 test RGB 32x32 uint8 images, converted per sample to float32 CHW in
 [0, 1] with int labels in [0, 100).  There is no network in this environment,
 so the default datasets are synthetic with the same shapes / dtypes / lengths
-(SURVEY §2.2 C5); a reader for the CIFAR-100 *binary* distribution
-(``cifar-100-binary/{train,test}.bin``, no pickle involved) is provided for
-machines that have the files.
+(SURVEY §2.2 C5); machines that have the files get the real set from either
+distribution: ``cifar-100-binary/{train,test}.bin`` (plain records) or
+``cifar-100-python/{train,test}`` -- the tree the reference's
+``download=True`` leaves in ``dataset/`` -- read by a loader that executes
+nothing from the file (``_load_cifar_python``).
 
 Every dataset implements ``__getitem__`` (ToTensor semantics) and the faster
 ``get_batch(indices)`` used by our loader (one gather instead of B Python
@@ -132,29 +134,143 @@ class CIFAR100Binary(_ArrayImageDataset):
         self.num_classes = 100
 
 
+# ---- the cifar-100-python layout without unpickling code ------------------------------------------------------------
+# torchvision's CIFAR100 leaves ``<root>/cifar-100-python/{train,test,meta}``: Python-2 pickles of a dict
+# {b"data": uint8 ndarray [N, 3072], b"fine_labels": [int], b"coarse_labels", b"filenames", b"batch_label"}.  A pickle
+# can name ANY importable callable; this reader lets the stream name exactly three -- the ones a numpy array pickles
+# as -- and resolves each to an inert stand-in defined here, so no function of numpy (or anything else) is called
+# on behalf of the file.  Everything else in the stream must be plain containers, bytes, str and ints; any other
+# global, a persistent id or an extension code raises.  The array is rebuilt from the raw buffer afterwards, with
+# its dtype and shape checked.
+import io
+import pickle
+
+
+class _NdStub:
+    """What ``numpy.core.multiarray._reconstruct`` + BUILD leave behind: the pickled array's state tuple."""
+
+    def __init__(self, *args):
+        self.state = None
+
+    def __setstate__(self, state):
+        self.state = state
+
+
+class _DtypeStub:
+    def __init__(self, *args):
+        self.args, self.state = args, None
+
+    def __setstate__(self, state):
+        self.state = state
+
+
+def _nd_reconstruct(cls, shape, typecode):
+    if cls is not _NdStub:
+        raise pickle.UnpicklingError("cifar-100-python: unexpected array class")
+    return _NdStub()
+
+
+def _latin1_bytes(text, encoding="latin1"):
+    """How Python 3 writes a ``bytes`` object at pickle protocol <= 2 (``_codecs.encode(str, 'latin1')``); the file the
+    reference's download leaves was written by Python 2 and holds plain string opcodes instead."""
+    if not isinstance(text, str) or str(encoding).lower().replace("-", "") != "latin1":
+        raise pickle.UnpicklingError("cifar-100-python: unexpected text encoding request")
+    return text.encode("latin1")
+
+
+_ALLOWED_GLOBALS = {
+    ("_codecs", "encode"): _latin1_bytes,
+    ("numpy.core.multiarray", "_reconstruct"): _nd_reconstruct,
+    ("numpy._core.multiarray", "_reconstruct"): _nd_reconstruct,
+    ("numpy", "ndarray"): _NdStub,
+    ("numpy", "dtype"): _DtypeStub,
+}
+
+
+class _InertUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        try:
+            return _ALLOWED_GLOBALS[(module, name)]
+        except KeyError:
+            raise pickle.UnpicklingError(f"cifar-100-python: the file names {module}.{name}; only plain containers and "
+                                         f"numpy arrays are read") from None
+
+    def persistent_load(self, pid):
+        raise pickle.UnpicklingError("cifar-100-python: persistent ids are not read")
+
+
+def _array_from_stub(stub: _NdStub, name: str) -> np.ndarray:
+    st = stub.state
+    if not (isinstance(st, tuple) and len(st) == 5):
+        raise ValueError(f"cifar-100-python: {name}: unexpected array state")
+    _, shape, dt, fortran, raw = st
+    if not (isinstance(dt, _DtypeStub) and dt.args and dt.args[0] in ("u1", b"u1", "uint8", "|u1")):
+        raise ValueError(f"cifar-100-python: {name}: expected a uint8 array")
+    if isinstance(raw, str):  # (a Python-2 str decoded as latin-1)
+        raw = raw.encode("latin1")
+    if not (isinstance(shape, tuple) and all(isinstance(d, int) and d >= 0 for d in shape)) or fortran:
+        raise ValueError(f"cifar-100-python: {name}: unexpected array layout")
+    if int(np.prod(shape, dtype=np.int64)) != len(raw):
+        raise ValueError(f"cifar-100-python: {name}: {len(raw)} bytes for shape {shape}")
+    return np.frombuffer(raw, dtype=np.uint8).reshape(shape)
+
+
+def _load_cifar_python(path: str):
+    """-> (uint8 [N, 3072] array, list of fine labels) from a ``cifar-100-python`` batch file."""
+    with open(path, "rb") as fh:
+        obj = _InertUnpickler(io.BytesIO(fh.read()), encoding="bytes").load()
+    if not isinstance(obj, dict):
+        raise ValueError("cifar-100-python: the file does not hold a dict")
+    obj = {(k.decode() if isinstance(k, bytes) else k): v for k, v in obj.items()}
+    data, labels = obj.get("data"), obj.get("fine_labels")
+    if not isinstance(data, _NdStub) or not isinstance(labels, list) or not all(isinstance(v, int) for v in labels):
+        raise ValueError("cifar-100-python: expected keys data (uint8 array) and fine_labels (list of ints)")
+    arr = _array_from_stub(data, "data")
+    if arr.ndim != 2 or arr.shape[1] != 3072 or arr.shape[0] != len(labels):
+        raise ValueError(f"cifar-100-python: data {arr.shape} does not match {len(labels)} labels of 3x32x32 images")
+    return arr, labels
+
+
+class CIFAR100Python(_ArrayImageDataset):
+    """Real CIFAR-100 from ``<root>/cifar-100-python/{train,test}``, the layout ``torchvision.datasets.CIFAR100(
+    root, download=True)`` of the reference (``/root/reference/main.py:42-51``) leaves on disk.  Fine labels."""
+
+    def __init__(self, root: str = "dataset", train: bool = True):
+        path = os.path.join(root, "cifar-100-python", "train" if train else "test")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not found")
+        arr, labels = _load_cifar_python(path)
+        imgs = torch.from_numpy(arr.reshape(-1, 3, 32, 32).copy()).permute(0, 2, 3, 1).contiguous()
+        super().__init__(imgs, torch.tensor(labels, dtype=torch.int64))
+        self.num_classes = 100
+
+
 def build_dataset(name: str, train: bool = True, root: str = "dataset", num_classes: int | None = None,
                   length: int | None = None, seed: int = 0):
     name = name.lower()
     if name in ("cifar100", "cifar-100"):
         path = os.path.join(root, "cifar-100-binary", "train.bin" if train else "test.bin")
-        found = os.path.exists(path)
+        py_path = os.path.join(root, "cifar-100-python", "train" if train else "test")
+        kind = 2 if os.path.exists(path) else (1 if os.path.exists(py_path) else 0)  # binary preferred
+        found = kind > 0
         # every rank must train on the same source: agree on "every rank has the files" (one MIN all-reduce), so a
         # node without them turns the whole job to the synthetic set instead of silently feeding different data
         import torch.distributed as tdist
 
         if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
             dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
-            flag = torch.tensor([1 if found else 0], dtype=torch.int32, device=dev)
-            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
-            everywhere = bool(flag.item())
+            flag = torch.tensor([kind], dtype=torch.int32, device=dev)
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)  # (the two layouts hold the same images in the same order)
+            everywhere = int(flag.item()) > 0
             if found and not everywhere:
-                sys.stderr.write(f"[pdt] {path} exists here but not on every rank: all ranks use synthetic data\n")
+                sys.stderr.write(f"[pdt] CIFAR-100 files exist under {root} here but not on every rank: all ranks use "
+                                 f"synthetic data\n")
             found = everywhere
         if found:
-            return CIFAR100Binary(root, train)
+            return CIFAR100Binary(root, train) if kind == 2 else CIFAR100Python(root, train)
         if not tdist.is_initialized() or tdist.get_rank() == 0:
-            sys.stderr.write(f"[pdt] NOTICE: {path} not found (no network to download CIFAR-100): using SYNTHETIC "
-                             f"CIFAR-100-shaped data; results are not CIFAR-100 results\n")
+            sys.stderr.write(f"[pdt] NOTICE: neither {path} nor {py_path} found (no network to download CIFAR-100): "
+                             f"using SYNTHETIC CIFAR-100-shaped data; results are not CIFAR-100 results\n")
             sys.stderr.flush()
         # same shapes, dtypes and length as the reference's dataset
         return SyntheticCIFAR(train, num_classes or 100, length, seed=seed)

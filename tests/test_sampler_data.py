@@ -173,3 +173,63 @@ def test_loader_raw_uint8_batches_match_the_totensor_path():
     for (xa, ya), (xb, yb) in zip(a, b):
         assert torch.equal(ya, yb)
         assert torch.allclose(Engine.prepare_input(eng, xb), xa, atol=1e-7)
+
+
+def _py2_cifar_pickle(data, fine):
+    """A pickle as Python 2's cPickle (protocol 2) writes the CIFAR-100 batch dict: string opcodes for keys and the
+    raw buffer, ``numpy.core.multiarray._reconstruct`` + BUILD for the array (what torchvision's download leaves)."""
+    import struct
+
+    def sstr(b):  # SHORT_BINSTRING
+        return b"U" + bytes([len(b)]) + b
+    n, w = data.shape
+    arr = (b"cnumpy.core.multiarray\n_reconstruct\n" + b"cnumpy\nndarray\n" + b"K\x00\x85" + sstr(b"b") + b"\x87R"
+           + b"(K\x01" + b"(" + b"K" + bytes([n]) + b"M" + struct.pack("<H", w) + b"t"
+           + b"cnumpy\ndtype\n" + sstr(b"u1") + b"K\x00K\x01\x87R" + b"(K\x03" + sstr(b"|") + b"NNN" + b"J\xff\xff\xff\xff" * 2
+           + b"K\x00tb" + b"\x89" + b"T" + struct.pack("<i", data.size) + data.tobytes() + b"tb")
+    labels = b"]" + b"(" + b"".join(b"K" + bytes([v]) for v in fine) + b"e"
+    return (b"\x80\x02}(" + sstr(b"data") + arr + sstr(b"fine_labels") + labels + sstr(b"coarse_labels") + labels
+            + sstr(b"batch_label") + sstr(b"training batch 1 of 1") + b"u.")
+
+
+def test_cifar100_python_layout_is_read_without_running_pickled_code(tmp_path):
+    """The tree the reference's ``CIFAR100(root='dataset', download=True)`` leaves (``/root/reference/main.py:42-51``):
+    read through an unpickler whose only resolvable globals are inert stand-ins for numpy's array pickling."""
+    import os
+    import pickle
+
+    import numpy as np
+
+    from pytorch_distributed_training_amd.data import build_dataset
+    from pytorch_distributed_training_amd.data.datasets import CIFAR100Python
+
+    rng = np.random.default_rng(0)
+    data = rng.integers(0, 256, (12, 3072), dtype=np.uint8)
+    fine = [int(v) for v in rng.integers(0, 100, 12)]
+    d = tmp_path / "cifar-100-python"
+    d.mkdir()
+    for name in ("train", "test"):
+        (d / name).write_bytes(_py2_cifar_pickle(data, fine))
+    pickle.loads(_py2_cifar_pickle(data, fine), encoding="bytes")  # the hand-built stream is a valid numpy pickle
+    ds = build_dataset("cifar100", train=True, root=str(tmp_path))
+    assert isinstance(ds, CIFAR100Python) and len(ds) == 12 and ds.num_classes == 100
+    img, label = ds[5]
+    assert label == fine[5] and img.shape == (3, 32, 32)
+    assert np.array_equal((img * 255).round().numpy().astype(np.uint8), data[5].reshape(3, 32, 32))
+    # a Python-3 protocol-4 dump of the same dict reads the same
+    (d / "train").write_bytes(pickle.dumps({b"data": data, b"fine_labels": fine}, protocol=4))
+    assert torch.equal(CIFAR100Python(str(tmp_path)).images, ds.images)
+
+    # anything else a pickle could name is refused before it is called
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > " + str(tmp_path / "pwned"),))
+
+    (d / "train").write_bytes(pickle.dumps({b"data": Evil(), b"fine_labels": fine}, protocol=2))
+    with pytest.raises(pickle.UnpicklingError, match="only plain containers"):
+        CIFAR100Python(str(tmp_path))
+    assert not (tmp_path / "pwned").exists()
+    # a float64 array where the images should be
+    (d / "train").write_bytes(pickle.dumps({b"data": data.astype(np.float64), b"fine_labels": fine}, protocol=2))
+    with pytest.raises(ValueError, match="uint8"):
+        CIFAR100Python(str(tmp_path))
