@@ -320,10 +320,10 @@ def check_bn(B, C, H, W, time_it):
     run_case(f"bn_bwd {tag}", bwd)
 
 
-def check_attention(B, S, H, time_it):
-    tag = f"B{B} S{S} H{H}"
-    qkv = torch.randn(B, S, 3 * H * 64, device=DEV).to(torch.bfloat16)
-    dout = torch.randn(B, S, H * 64, device=DEV).to(torch.bfloat16)
+def check_attention(B, S, H, time_it, hd=64):
+    tag = f"B{B} S{S} H{H}" + ("" if hd == 64 else f" hd{hd}")
+    qkv = torch.randn(B, S, 3 * H * hd, device=DEV).to(torch.bfloat16)
+    dout = torch.randn(B, S, H * hd, device=DEV).to(torch.bfloat16)
 
     def run():
         out, lse = native.attention_fwd(qkv, H)
@@ -335,7 +335,7 @@ def check_attention(B, S, H, time_it):
         record(f"attention_fwd {tag}", e < 2e-2, e, extra)
         dqkv = native.attention_bwd(dout, qkv, out, lse, H)
         dr = reference.attention_bwd(dout.float(), qkv.float(), outr, lser, H)
-        d = 3 * H * 64
+        d = 3 * H * hd
         parts = {"dq": slice(0, d // 3), "dk": slice(d // 3, 2 * d // 3), "dv": slice(2 * d // 3, d)}
         errs = {k: rel_err(dqkv[..., sl], dr[..., sl]) for k, sl in parts.items()}
         extra = dict(errs)

@@ -49,7 +49,8 @@ def get_parser() -> argparse.ArgumentParser:
     p.add_argument("--epochs", default=2, type=int)
     p.add_argument("--lr", default=0.001, type=float)
     p.add_argument("--model", default="resnet50",
-                   choices=["resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "vit_b_16", "vit_tiny_test"])
+                   choices=["resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "vit_b_16", "vit_ti_16", "vit_s_16", "vit_l_16",
+                            "vit_tiny_test"])
     p.add_argument("--dataset", default="cifar100",
                    choices=["cifar100", "synthetic-cifar", "synthetic-cifar10", "synthetic-imagenet"])
     p.add_argument("--data_root", default="dataset", type=str)

@@ -1012,35 +1012,55 @@ void check_attn(const Tensor& t, const char* name) {
     TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, ": data pointer must be 16-B aligned");
 }
 
-// qkv [B, S, 3*H*64] (packed q | k | v, heads inside) -> (out [B, S, H*64], lse [B, H, S])
+// qkv [B, S, 3*H*hd] (packed q | k | v, heads inside) -> (out [B, S, H*hd], lse [B, H, S]); hd in {32, 64, 128}
+static long attn_head_dim(const Tensor& qkv, int64_t heads) {
+    const long D = qkv.size(2) / 3;
+    TORCH_CHECK(qkv.size(2) == 3 * D && heads > 0 && D % heads == 0, "attention: width must be 3 * heads * head_dim");
+    const long hd = D / heads;
+    TORCH_CHECK(attention_shape_ok((int)qkv.size(1), (int)hd), "attention: head_dim ", hd, " / sequence length ", qkv.size(1),
+                " not supported (head_dim 32, 64 or 128)");
+    return hd;
+}
+
 std::tuple<Tensor, Tensor> attention_fwd(const Tensor& qkv, int64_t heads) {
     check_attn(qkv, "qkv");
     const long B = qkv.size(0), S = qkv.size(1), D = qkv.size(2) / 3;
-    TORCH_CHECK(qkv.size(2) == 3 * D && heads > 0 && D == heads * 64, "attention: width must be 3 * heads * 64");
-    TORCH_CHECK(attention_shape_ok((int)S, 64), "attention: sequence length ", S, " not supported (<= 256)");
-    TORCH_CHECK(B * heads < (1L << 31), "too many (batch, head) pairs");
+    const long hd = attn_head_dim(qkv, heads);
     c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
     Tensor out = at::empty({B, S, D}, qkv.options());
     Tensor lse = at::empty({B, heads, S}, qkv.options().dtype(at::kFloat));
-    if (B > 0)
-        launch_attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr<float>(), (int)B, (int)S, (int)heads,
-                             cur_stream(qkv));
+    // the grid's second dimension carries (batch, head): cut the batch where that would pass 65535
+    const long per = std::max<long>(1, 65535 / heads);
+    for (long b0 = 0; b0 < B; b0 += per) {
+        const long nb = std::min(per, B - b0);
+        launch_attention_fwd(static_cast<const char*>(qkv.data_ptr()) + b0 * S * 3 * D * 2,
+                             static_cast<char*>(out.data_ptr()) + b0 * S * D * 2, lse.data_ptr<float>() + b0 * heads * S,
+                             (int)nb, (int)S, (int)heads, (int)hd, cur_stream(qkv));
+    }
     return {out, lse};
 }
 
 Tensor attention_bwd(const Tensor& dout, const Tensor& qkv, const Tensor& out, const Tensor& lse, int64_t heads) {
     check_attn(qkv, "qkv"); check_attn(out, "out"); check_attn(dout, "dout");
     const long B = qkv.size(0), S = qkv.size(1), D = qkv.size(2) / 3;
-    TORCH_CHECK(qkv.size(2) == 3 * D && D == heads * 64, "attention: width must be 3 * heads * 64");
+    const long hd = attn_head_dim(qkv, heads);
     TORCH_CHECK(out.size(0) == B && out.size(1) == S && out.size(2) == D && dout.sizes() == out.sizes(), "out / dout shape");
     TORCH_CHECK(lse.is_cuda() && lse.scalar_type() == at::kFloat && lse.is_contiguous() && lse.numel() == B * heads * S,
                 "lse: expected contiguous fp32 [B, H, S]");
-    TORCH_CHECK(attention_shape_ok((int)S, 64), "attention: sequence length ", S, " not supported (<= 256)");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
     Tensor dqkv = at::empty_like(qkv);
-    if (B > 0)
-        launch_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr<float>(), dqkv.data_ptr(),
-                             (int)B, (int)S, (int)heads, cur_stream(qkv));
+    Tensor dsum;
+    if (attention_needs_dsum((int)S, (int)hd)) dsum = at::empty({B, heads, S}, lse.options());
+    const long per = std::max<long>(1, 65535 / heads);
+    for (long b0 = 0; b0 < B; b0 += per) {
+        const long nb = std::min(per, B - b0);
+        launch_attention_bwd(static_cast<const char*>(qkv.data_ptr()) + b0 * S * 3 * D * 2,
+                             static_cast<const char*>(out.data_ptr()) + b0 * S * D * 2,
+                             static_cast<const char*>(dout.data_ptr()) + b0 * S * D * 2, lse.data_ptr<float>() + b0 * heads * S,
+                             static_cast<char*>(dqkv.data_ptr()) + b0 * S * 3 * D * 2,
+                             dsum.defined() ? dsum.data_ptr<float>() + b0 * heads * S : nullptr, (int)nb, (int)S, (int)heads,
+                             (int)hd, cur_stream(qkv));
+    }
     return dqkv;
 }
 

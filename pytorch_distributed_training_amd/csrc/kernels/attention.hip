@@ -1,5 +1,6 @@
-// Fused multi-head self-attention (forward + backward) for short sequences on the gfx950 matrix cores.
-// ViT: 197 tokens, head_dim 64, no mask, no dropout.
+// Fused multi-head self-attention (forward + backward) on the gfx950 matrix cores, no mask, no dropout.
+// Two families: whole-head kernels for short sequences at head_dim 64 (ViT-B/16: 197 tokens; the flagship path),
+// and key-/query-block streaming kernels for any length at head_dim 32 / 64 / 128 (second half of the file).
 //
 //   qkv : [B, S, 3, H, 64] bf16  (the packed in-projection output, read in place: no permute copies)
 //   out : [B, S, H, 64]    bf16  (= [B, S, D], what the out-projection GEMM wants)
@@ -21,6 +22,9 @@
 //  * softmax scale 1/8 is folded into Q when it is staged (exact in bf16).
 //  * deterministic: no atomics; the backward recomputes the scores once per pass (dK/dV pass with a wave
 //    per key tile, dQ pass with a wave per query tile) instead of reducing dQ across waves.
+#include <cmath>
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -329,6 +333,356 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd(const bf16* __restrict__ q
     }
 }
 
+// ============================================================================= any length, head_dim 32 / 64 / 128
+// The kernels above keep a head's whole K / V (and its score row) on chip, which stops at 256 tokens and is built for
+// head_dim 64.  The kernels below are the general path (ViT at 384 x 384: 577 tokens; ViT-Tiny: 3 heads of 64 ...
+// head_dim 32 / 128 models): a workgroup owns 128 queries (or keys) of one head, one 32-row tile per wave, and the
+// OTHER axis streams through LDS in blocks of 64 rows, so the sequence length is unbounded and LDS use is fixed
+// (<= 32 KiB + 512 B).  Same MFMA dataflow as above (scores as accumulators feeding the next MFMA from registers).
+//  * forward in two sweeps over the keys: sweep 1 = running row max + rescaled row sum (scalars per lane, no
+//    accumulator rescaling, no data-dependent branch), sweep 2 = P = exp(s - lse) already normalised, O += P V.
+//    1.5x the matrix work of a one-sweep online softmax, on a path whose job is generality.
+//  * backward as two kernels (key-owner: dK, dV; query-owner: dQ) with D[q] = sum_d dO * O from a small pre-pass.
+//  * the softmax scale is applied to the fp32 scores (1/sqrt(32) is not a bf16 number).
+template <int HDT>
+struct AttnGeo {
+    static constexpr int ROWBYTES = HDT * 2, NCH = HDT / 8, STEPS = HDT / 16, DT = HDT / 32;
+    static __device__ __forceinline__ int swz(int row, int chunk) {
+        const int x = ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) & (NCH - 1);
+        return row * ROWBYTES + ((chunk ^ x) << 4);
+    }
+    static __device__ __forceinline__ bf16x8 rows(const char* img, int row, int step, int half) {
+        return *reinterpret_cast<const bf16x8*>(img + swz(row, 2 * step + half));
+    }
+    static __device__ __forceinline__ bf16x8 cols(const char* img, int r0, int colbase, int lane) {
+        const int q4 = (lane & 15) >> 2, p = lane & 3, h16 = (lane >> 4) & 1, half = lane >> 5;
+        const int col = colbase + h16 * 16 + p * 4;
+        const int ra = r0 + 4 * half + q4, rb = ra + 8;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + swz(ra, col >> 3) + (col & 7) * 2));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + swz(rb, col >> 3) + (col & 7) * 2));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    // rows [r0, r0 + 64) of a [*, row_stride] tensor -> LDS image rows 0..63 (zeros past S); 256 threads
+    static __device__ __forceinline__ void stage64(char* img, const bf16* src, long row_stride, int r0, int S, int tid) {
+        for (int i = tid; i < 64 * NCH; i += 256) {
+            const int row = i / NCH, ch = i % NCH;
+            bf16x8 v;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (bf16)0.f;
+            if (r0 + row < S) v = *reinterpret_cast<const bf16x8*>(src + (long)(r0 + row) * row_stride + ch * 8);
+            *reinterpret_cast<bf16x8*>(img + swz(row, ch)) = v;
+        }
+    }
+    // a wave's own 32 rows as MFMA fragments straight from global memory (lane = row, 8 elements per step and half)
+    static __device__ __forceinline__ void own_rows(bf16x8* f, const bf16* src, long row_stride, int row, int S, int half) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[s][k] = (bf16)0.f;
+            if (row < S) f[s] = *reinterpret_cast<const bf16x8*>(src + (long)row * row_stride + s * 16 + half * 8);
+        }
+    }
+};
+
+template <int HDT>
+__global__ __launch_bounds__(256) void k_attn_fwd_kb(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                     float* __restrict__ lse, int S, int H, float scale) {
+    using G = AttnGeo<HDT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + 64 * G::ROWBYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const long D = (long)H * HDT, rs = 3 * D;
+    const bf16* base = qkv + (long)b * S * rs + h * HDT;
+    const int q0 = blockIdx.x * 128 + wave * 32, q = q0 + l31;
+    bf16x8 bq[G::STEPS];
+    G::own_rows(bq, base, rs, q, S, half);
+    const int nkb = (S + 63) / 64;
+
+    // sweep 1: row max and row sum
+    float m = kNegBig, sum = 0.f;
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+        G::stage64(Ks, base + D, rs, kb * 64, S, tid);
+        __syncthreads();
+        f32x16 st[2];
+        float mb = kNegBig;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < G::STEPS; ++s)
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G::rows(Ks, kt * 32 + l31, s, half), bq[s], st[kt], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[kt][r] = kb * 64 + kt * 32 + acc_row(r, half) < S ? st[kt][r] * scale : kNegBig;
+                mb = fmaxf(mb, st[kt][r]);
+            }
+        }
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        const float mn = fmaxf(m, mb);
+        float part = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part += __expf(st[kt][r] - mn);
+        sum = sum * __expf(m - mn) + part;
+        m = mn;
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float lq = m + __logf(sum);
+    if (q < S && half == 0) lse[((long)b * H + h) * S + q] = lq;
+
+    // sweep 2: O = softmax(S) V with the final normaliser
+    f32x16 o[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+        G::stage64(Ks, base + D, rs, kb * 64, S, tid);
+        G::stage64(Vs, base + 2 * D, rs, kb * 64, S, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < G::STEPS; ++s)
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G::rows(Ks, kt * 32 + l31, s, half), bq[s], st, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                st[r] = kb * 64 + kt * 32 + acc_row(r, half) < S ? __expf(st[r] * scale - lq) : 0.f;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const bf16x8 pa = acc_to_a(st, blk);
+#pragma unroll
+                for (int dt = 0; dt < G::DT; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, G::cols(Vs, kt * 32 + blk * 16, dt * 32, lane), o[dt], 0, 0, 0);
+            }
+        }
+    }
+    bf16* orow = out + ((long)b * S * H + h) * HDT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + acc_row(r, half);
+        if (qq < S) {
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) orow[(long)qq * D + dt * 32 + l31] = (bf16)o[dt][r];
+        }
+    }
+}
+
+// D[b, h, q] = sum_d dO * O; one thread per (b, q, h)
+template <int HDT>
+__global__ __launch_bounds__(256) void k_attn_dsum(const bf16* __restrict__ out, const bf16* __restrict__ dout,
+                                                   float* __restrict__ dsum, long total, int S, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (b * S + q) * H + h
+    if (i >= total) return;
+    const int h = (int)(i % H);
+    const long bq = i / H;
+    const int q = (int)(bq % S);
+    const long b = bq / S;
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < HDT / 8; ++c) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(out + i * HDT + c * 8);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dout + i * HDT + c * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d += (float)a[k] * (float)g[k];
+    }
+    dsum[(b * H + h) * S + q] = d;
+}
+
+// a wave owns 32 KEYS; queries stream through LDS -> dK, dV
+template <int HDT>
+__global__ __launch_bounds__(256) void k_attn_bwd_kv(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                     const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                     bf16* __restrict__ dqkv, int S, int H, float scale) {
+    using G = AttnGeo<HDT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* Os = smem + 64 * G::ROWBYTES;
+    float* Ls = reinterpret_cast<float*>(Os + 64 * G::ROWBYTES);
+    float* Ds = Ls + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const long D = (long)H * HDT, rs = 3 * D;
+    const bf16* base = qkv + (long)b * S * rs + h * HDT;
+    const bf16* dobase = dout + ((long)b * S * H + h) * HDT;
+    const float* lrow = lse + ((long)b * H + h) * S;
+    const float* drow = dsum + ((long)b * H + h) * S;
+    const int k0 = blockIdx.x * 128 + wave * 32, key = k0 + l31;
+    bf16x8 kf[G::STEPS], vf[G::STEPS];
+    G::own_rows(kf, base + D, rs, key, S, half);
+    G::own_rows(vf, base + 2 * D, rs, key, S, half);
+    f32x16 dk[G::DT], dv[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dk[dt][r] = 0.f;
+            dv[dt][r] = 0.f;
+        }
+    const int nqb = (S + 63) / 64;
+    for (int qb = 0; qb < nqb; ++qb) {
+        __syncthreads();
+        G::stage64(Qs, base, rs, qb * 64, S, tid);
+        G::stage64(Os, dobase, D, qb * 64, S, tid);
+        if (tid < 64) {
+            const int q = qb * 64 + tid;
+            Ls[tid] = q < S ? lrow[q] : -kNegBig;  // huge on padding rows: P = 0 there
+            Ds[tid] = q < S ? drow[q] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x16 sc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = 0.f;
+                dp[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < G::STEPS; ++s) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G::rows(Qs, qt * 32 + l31, s, half), kf[s], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G::rows(Os, qt * 32 + l31, s, half), vf[s], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = qt * 32 + acc_row(r, half);
+                const float p = key < S ? __expf(sc[r] * scale - Ls[ql]) : 0.f;
+                sc[r] = p;
+                dp[r] = p * (dp[r] - Ds[ql]);
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const bf16x8 pa = acc_to_a(sc, blk), dsa = acc_to_a(dp, blk);
+#pragma unroll
+                for (int dt = 0; dt < G::DT; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, G::cols(Os, qt * 32 + blk * 16, dt * 32, lane), dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, G::cols(Qs, qt * 32 + blk * 16, dt * 32, lane), dk[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    bf16* dbase = dqkv + (long)b * S * rs + h * HDT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int kk = k0 + acc_row(r, half);
+        if (kk < S) {
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) {
+                dbase[(long)kk * rs + D + dt * 32 + l31] = (bf16)(dk[dt][r] * scale);
+                dbase[(long)kk * rs + 2 * D + dt * 32 + l31] = (bf16)dv[dt][r];
+            }
+        }
+    }
+}
+
+// a wave owns 32 QUERIES; keys stream through LDS -> dQ
+template <int HDT>
+__global__ __launch_bounds__(256) void k_attn_bwd_q(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                    const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                    bf16* __restrict__ dqkv, int S, int H, float scale) {
+    using G = AttnGeo<HDT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + 64 * G::ROWBYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const long D = (long)H * HDT, rs = 3 * D;
+    const bf16* base = qkv + (long)b * S * rs + h * HDT;
+    const bf16* dobase = dout + ((long)b * S * H + h) * HDT;
+    const int q0 = blockIdx.x * 128 + wave * 32, q = q0 + l31;
+    bf16x8 qf[G::STEPS], gf[G::STEPS];
+    G::own_rows(qf, base, rs, q, S, half);
+    G::own_rows(gf, dobase, D, q, S, half);
+    const float lq = q < S ? lse[((long)b * H + h) * S + q] : -kNegBig;
+    const float dq_row = q < S ? dsum[((long)b * H + h) * S + q] : 0.f;
+    f32x16 dq[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    const int nkb = (S + 63) / 64;
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+        G::stage64(Ks, base + D, rs, kb * 64, S, tid);
+        G::stage64(Vs, base + 2 * D, rs, kb * 64, S, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 sc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = 0.f;
+                dp[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < G::STEPS; ++s) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G::rows(Ks, kt * 32 + l31, s, half), qf[s], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G::rows(Vs, kt * 32 + l31, s, half), gf[s], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kb * 64 + kt * 32 + acc_row(r, half);
+                const float p = kk < S ? __expf(sc[r] * scale - lq) : 0.f;
+                dp[r] = p * (dp[r] - dq_row);
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const bf16x8 dsa = acc_to_a(dp, blk);
+#pragma unroll
+                for (int dt = 0; dt < G::DT; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, G::cols(Ks, kt * 32 + blk * 16, dt * 32, lane), dq[dt], 0, 0, 0);
+            }
+        }
+    }
+    bf16* dbase = dqkv + (long)b * S * rs + h * HDT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + acc_row(r, half);
+        if (qq < S) {
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) dbase[(long)qq * rs + dt * 32 + l31] = (bf16)(dq[dt][r] * scale);
+        }
+    }
+}
+
+template <int HDT>
+void launch_fwd_kb(const void* qkv, void* out, float* lse, int B, int S, int H, hipStream_t s) {
+    const size_t lds = (size_t)2 * 64 * HDT * 2;
+    hipLaunchKernelGGL((k_attn_fwd_kb<HDT>), dim3((S + 127) / 128, B * H), dim3(256), lds, s, (const bf16*)qkv, (bf16*)out, lse,
+                       S, H, 1.f / sqrtf((float)HDT));
+}
+template <int HDT>
+void launch_bwd_kb(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dsum, int B,
+                   int S, int H, hipStream_t s) {
+    const long total = (long)B * S * H;
+    const float scale = 1.f / sqrtf((float)HDT);
+    hipLaunchKernelGGL((k_attn_dsum<HDT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16*)out,
+                       (const bf16*)dout, dsum, total, S, H);
+    const size_t lds_kv = (size_t)2 * 64 * HDT * 2 + 2 * 64 * sizeof(float), lds_q = (size_t)2 * 64 * HDT * 2;
+    const dim3 grid((S + 127) / 128, B * H);
+    hipLaunchKernelGGL((k_attn_bwd_kv<HDT>), grid, dim3(256), lds_kv, s, (const bf16*)qkv, (const bf16*)dout, lse,
+                       (const float*)dsum, (bf16*)dqkv, S, H, scale);
+    hipLaunchKernelGGL((k_attn_bwd_q<HDT>), grid, dim3(256), lds_q, s, (const bf16*)qkv, (const bf16*)dout, lse,
+                       (const float*)dsum, (bf16*)dqkv, S, H, scale);
+}
+
+bool force_generic() {
+    static const bool on = [] {
+        const char* e = getenv("PDT_ATTN_GENERIC");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
 template <typename K>
 void set_lds(K kern, size_t bytes) {
     PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -337,9 +691,21 @@ void set_lds(K kern, size_t bytes) {
 
 }  // namespace
 
-bool attention_shape_ok(int S, int head_dim) { return head_dim == HD && S >= 1 && S <= 256; }
+bool attention_shape_ok(int S, int head_dim) {
+    return (head_dim == 32 || head_dim == 64 || head_dim == 128) && S >= 1 && (long)S < (1L << 24);
+}
+// the whole-head kernels (K / V resident in LDS, one sweep) take what they were built for; everything else streams
+static bool whole_head(int S, int head_dim) { return head_dim == HD && S <= 256 && !force_generic(); }
+bool attention_needs_dsum(int S, int head_dim) { return !whole_head(S, head_dim); }
 
-void launch_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, hipStream_t s) {
+void launch_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int head_dim, hipStream_t s) {
+    if (!attention_shape_ok(S, head_dim) || (long)B * H > 65535) abort();  // (the binding checks both)
+    if (!whole_head(S, head_dim)) {
+        if (head_dim == 32) launch_fwd_kb<32>(qkv, out, lse, B, S, H, s);
+        else if (head_dim == 64) launch_fwd_kb<64>(qkv, out, lse, B, S, H, s);
+        else launch_fwd_kb<128>(qkv, out, lse, B, S, H, s);
+        return;
+    }
     const int nt = (S + 31) / 32;
     const size_t lds = (size_t)2 * nt * 32 * ROWB;
 #define PDT_ATTN_FWD(N)                                                                                        \
@@ -357,8 +723,16 @@ void launch_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, 
 #undef PDT_ATTN_FWD
 }
 
-void launch_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
-                          int S, int H, hipStream_t s) {
+void launch_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dsum,
+                          int B, int S, int H, int head_dim, hipStream_t s) {
+    if (!attention_shape_ok(S, head_dim) || (long)B * H > 65535) abort();
+    if (!whole_head(S, head_dim)) {
+        if (dsum == nullptr) abort();
+        if (head_dim == 32) launch_bwd_kb<32>(qkv, out, dout, lse, dqkv, dsum, B, S, H, s);
+        else if (head_dim == 64) launch_bwd_kb<64>(qkv, out, dout, lse, dqkv, dsum, B, S, H, s);
+        else launch_bwd_kb<128>(qkv, out, dout, lse, dqkv, dsum, B, S, H, s);
+        return;
+    }
     const int nt = (S + 31) / 32;
     const size_t lds = (size_t)4 * nt * 32 * ROWB + (size_t)2 * nt * 32 * sizeof(float);
 #define PDT_ATTN_BWD(N)                                                                                      \

@@ -136,12 +136,14 @@ void launch_layernorm_bwd(const void* dy, const void* x, const float* mean, cons
                           void* dx, float* slab, int blocks, long M, int D, const void* addend /* or null */,
                           hipStream_t s);
 
-// ---- fused self-attention, head_dim 64, S <= 256 (attention.hip) -----------------------------------
+// ---- fused self-attention (attention.hip): head_dim 32 / 64 / 128, any sequence length ------------------
+// (head_dim 64 up to 256 tokens runs the whole-head kernels, everything else the block-streaming ones)
 bool attention_shape_ok(int S, int head_dim);
-// qkv [B,S,3,H,64] bf16 -> out [B,S,H,64] bf16, lse [B,H,S] fp32
-void launch_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, hipStream_t s);
-void launch_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
-                          int S, int H, hipStream_t s);
+bool attention_needs_dsum(int S, int head_dim);  // backward wants an fp32 [B,H,S] scratch (block-streaming kernels)
+// qkv [B,S,3,H,hd] bf16 -> out [B,S,H,hd] bf16, lse [B,H,S] fp32; B * H <= 65535
+void launch_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int head_dim, hipStream_t s);
+void launch_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                          float* dsum /* [B,H,S] or null */, int B, int S, int H, int head_dim, hipStream_t s);
 
 // ---- pools (NHWC bf16) -----------------------------------------------------------------------
 void launch_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int B, int H, int W, int C, int Ho, int Wo,

@@ -1,6 +1,8 @@
 // LayerNorm over the last dimension for token-major activations [M, D] (ViT: D = 768), bf16 in / bf16 out,
 // fp32 statistics and affine parameters.
 //
+// Any width D % 4 == 0 up to 2048 (ViT-Tiny 192 ... ViT-Huge 1280 and beyond): the kernels are built per piece COUNT
+// NP = ceil(D / 256) and mask the pieces past the end of a row, so D = 768 still runs the exact-fit code.
 // One wave per row: D / 64 elements per lane as 8-byte (4 x bf16) pieces, so a row is read ONCE into
 // registers, mean and variance are two in-register passes (no E[x^2] - E[x]^2 cancellation) and the
 // normalised row is written straight back: 2 bytes read + 2 bytes written per element, against the
@@ -14,42 +16,45 @@
 namespace pdt {
 namespace {
 
-constexpr int kMaxPieces = 16;  // D <= 4096
+constexpr int kMaxPieces = 8;  // D <= 2048
 
 template <int NP>
 __global__ __launch_bounds__(256) void k_ln_fwd(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, bf16* __restrict__ y,
                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out, long M,
-                                                float eps) {
-    constexpr int D = NP * 256;
+                                                int D, float eps) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
+    const int np4 = D >> 2;  // pieces of the row; piece lane + 64 j exists iff it is below
+    const float inv_d = 1.f / (float)D;
     const bf16x4* xr = reinterpret_cast<const bf16x4*>(x + row * D);
     float v[NP][4];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const bf16x4 t = xr[lane + 64 * j];
+        bf16x4 t = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+        if (lane + 64 * j < np4) t = xr[lane + 64 * j];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             v[j][k] = (float)t[k];
             s += v[j][k];
         }
     }
-    const float mean = wave_sum(s) * (1.f / D);
+    const float mean = wave_sum(s) * inv_d;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < NP; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float d = v[j][k] - mean;
+            const float d = lane + 64 * j < np4 ? v[j][k] - mean : 0.f;
             q += d * d;
         }
-    const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + eps);
+    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
     bf16x4* yr = reinterpret_cast<bf16x4*>(y + row * D);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
+        if (lane + 64 * j >= np4) break;
         const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[lane + 64 * j];
         const f32x4 b = reinterpret_cast<const f32x4*>(beta)[lane + 64 * j];
         bf16x4 o;
@@ -67,15 +72,18 @@ template <int NP>
 __global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                 const float* __restrict__ gamma, bf16* __restrict__ dx,
-                                                float* __restrict__ slab /*[gridDim.x][2][D]*/, long M,
+                                                float* __restrict__ slab /*[gridDim.x][2][D]*/, long M, int D,
                                                 const bf16* __restrict__ addend /* or null: added to dx */) {
-    constexpr int D = NP * 256;
-    __shared__ float red[3][2][D];  // waves 1..3 park their column sums here
+    constexpr int DP = NP * 256;
+    __shared__ float red[3][2][DP];  // waves 1..3 park their column sums here
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int np4 = D >> 2;
+    const float inv_d = 1.f / (float)D;
     float g[NP][4], dgam[NP][4], dbet[NP][4];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const f32x4 t = reinterpret_cast<const f32x4*>(gamma)[lane + 64 * j];
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (lane + 64 * j < np4) t = reinterpret_cast<const f32x4*>(gamma)[lane + 64 * j];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             g[j][k] = t[k];
@@ -91,12 +99,16 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, con
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const bf16x4 tx = xr[lane + 64 * j];
-            const bf16x4 td = dr[lane + 64 * j];
+            const bool in = lane + 64 * j < np4;
+            bf16x4 tx = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, td = tx;
+            if (in) {
+                tx = xr[lane + 64 * j];
+                td = dr[lane + 64 * j];
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float d = (float)td[k];
-                xh[j][k] = ((float)tx[k] - mu) * rs;
+                xh[j][k] = in ? ((float)tx[k] - mu) * rs : 0.f;
                 gg[j][k] = d * g[j][k];
                 s1 += gg[j][k];
                 s2 += gg[j][k] * xh[j][k];
@@ -104,13 +116,14 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, con
                 dbet[j][k] += d;
             }
         }
-        const float c1 = wave_sum(s1) * (1.f / D), c2 = wave_sum(s2) * (1.f / D);
+        const float c1 = wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
         bf16x4* ox = reinterpret_cast<bf16x4*>(dx + row * D);
         // the gradient that reaches the same tensor through the residual connection joins here (pre-LN
         // transformer block: d(x) = d(skip) + LN'(d(branch))) instead of in a separate elementwise add
         const bf16x4* ar = addend ? reinterpret_cast<const bf16x4*>(addend + row * D) : nullptr;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
+            if (lane + 64 * j >= np4) break;
             bf16x4 o;
             if (ar) {
                 const bf16x4 ta = ar[lane + 64 * j];
@@ -137,6 +150,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, con
         float* out = slab + (long)blockIdx.x * 2 * D;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
+            if (lane + 64 * j >= np4) break;
             f32x4 ob, og;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -152,34 +166,33 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, con
 
 }  // namespace
 
-bool layernorm_dim_ok(int D) { return D == 256 || D == 512 || D == 768 || D == 1024 || D == 1280; }
+bool layernorm_dim_ok(int D) { return D >= 4 && D % 4 == 0 && D <= kMaxPieces * 256; }
 
 int layernorm_bwd_blocks(long M) {
     long b = (M + 3) / 4;
     return (int)(b < 512 ? b : 512);
 }
 
-#define PDT_LN_DISPATCH(D, CALL)                        \
-    switch (D) {                                        \
-        case 256: { constexpr int NP = 1; CALL; } break;  \
-        case 512: { constexpr int NP = 2; CALL; } break;  \
-        case 768: { constexpr int NP = 3; CALL; } break;  \
-        case 1024: { constexpr int NP = 4; CALL; } break; \
-        case 1280: { constexpr int NP = 5; CALL; } break; \
-        default: abort();                               \
+#define PDT_LN_CASE(N, ...) case N: { constexpr int NP = N; __VA_ARGS__; } break;
+#define PDT_LN_DISPATCH(D, ...)                                                                                   \
+    switch (((D) + 255) / 256) {                                                                                  \
+        PDT_LN_CASE(1, __VA_ARGS__) PDT_LN_CASE(2, __VA_ARGS__) PDT_LN_CASE(3, __VA_ARGS__) PDT_LN_CASE(4, __VA_ARGS__) \
+        PDT_LN_CASE(5, __VA_ARGS__) \
+        PDT_LN_CASE(6, __VA_ARGS__) PDT_LN_CASE(7, __VA_ARGS__) PDT_LN_CASE(8, __VA_ARGS__) \
+        default: abort();                                                                                         \
     }
 
 void launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                           long M, int D, float eps, hipStream_t s) {
     const unsigned grid = (unsigned)((M + 3) / 4);
     PDT_LN_DISPATCH(D, hipLaunchKernelGGL((k_ln_fwd<NP>), dim3(grid), dim3(256), 0, s, (const bf16*)x, gamma, beta,
-                                          (bf16*)y, mean, rstd, M, eps));
+                                          (bf16*)y, mean, rstd, M, D, eps));
 }
 
 void launch_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                           void* dx, float* slab, int blocks, long M, int D, const void* addend, hipStream_t s) {
     PDT_LN_DISPATCH(D, hipLaunchKernelGGL((k_ln_bwd<NP>), dim3(blocks), dim3(256), 0, s, (const bf16*)dy,
-                                          (const bf16*)x, mean, rstd, gamma, (bf16*)dx, slab, M, (const bf16*)addend));
+                                          (const bf16*)x, mean, rstd, gamma, (bf16*)dx, slab, M, D, (const bf16*)addend));
 }
 
 }  // namespace pdt

@@ -268,7 +268,13 @@ void Reducer::launch(Bucket& b) {
             PDT_HIP(hipEventRecord(b.done, rccl_->stream()));
             b.done_iter = iteration_;
         } else {
-            std::vector<at::Tensor> ts{b.flat};
+            // GPU buckets on a c10d group without RCCL (gloo: the one-GPU rehearsal of W > 1) are staged through the
+            // host HERE, with a synchronous copy on the compute stream, and the collective runs on the CPU copy.
+            // Handing gloo the GPU tensor makes it stage on its own pool streams with worker threads that block
+            // in hipStreamSynchronize while this thread blocks in the next small collective; with more streams
+            // than hardware queues that stopped two ranks sharing a GPU (profiles/r3_w2_hang.md).
+            if (is_cuda_) b.host = b.flat.to(at::kCPU);
+            std::vector<at::Tensor> ts{is_cuda_ ? b.host : b.flat};
             c10d::AllreduceOptions opts;
             opts.reduceOp = c10d::ReduceOp::SUM;
             if (trace_coll()) fprintf(stderr, "[coll r%d %.4f] bucket%zu it%ld issue\n", pg_->getRank(), mono_s(), bidx, (long)iteration_);
@@ -327,6 +333,10 @@ void Reducer::finalize() {
                     if (trace_coll()) fprintf(stderr, "[coll r%d %.4f] bucket%zu it%ld wait\n", pg_->getRank(), mono_s(), bidx, (long)iteration_);
                     b.work->wait();
                     b.work.reset();
+                    if (b.host.defined()) {
+                        b.flat.copy_(b.host);
+                        b.host.reset();
+                    }
                     if (trace_coll()) fprintf(stderr, "[coll r%d %.4f] bucket%zu it%ld done\n", pg_->getRank(), mono_s(), bidx, (long)iteration_);
                 }
         }

@@ -79,6 +79,7 @@ class Reducer {
         std::vector<char> ready;
         int64_t pending = 0;
         c10::intrusive_ptr<c10d::Work> work;
+        at::Tensor host;  // GPU bucket on a group without RCCL: the CPU copy the collective runs on
         hipEvent_t done = nullptr;
         hipEvent_t t0 = nullptr, t1 = nullptr;  // timing mode only
         bool launched = false;

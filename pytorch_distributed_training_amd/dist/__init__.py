@@ -192,6 +192,39 @@ def shutdown(engine=None, timeout_s: float = 60.0) -> None:
         done.set()
 
 
+def staged_through_host(tensor: torch.Tensor, group=None) -> bool:
+    """GPU tensor on a group whose backend is not RCCL (gloo: the one-GPU rehearsal of W > 1, or a GPU job forced onto
+    ``--backend gloo``).  c10d's gloo backend would move it through the host on its OWN pool streams and worker threads
+    (a worker thread blocks in ``hipStreamSynchronize`` while the caller blocks in ``work.wait()``); with more HIP
+    streams than hardware queues (``GPU_MAX_HW_QUEUES``, 4 by default) two ranks sharing a GPU stopped in backward in
+    2 runs of 2, and in 0 of 4 with 16 queues (``profiles/r3_w2_hang.md``).  Such tensors are therefore staged by US:
+    a synchronous copy to the host on the current stream, the collective on the CPU tensor, a copy back.  No pool
+    stream, no worker thread that waits for the device."""
+    return tensor.is_cuda and tdist.get_backend(group) != "nccl"
+
+
+def all_reduce_(tensor: torch.Tensor, group=None, op=None) -> torch.Tensor:
+    """``tdist.all_reduce`` in place, host-staged where :func:`staged_through_host` says so."""
+    op = tdist.ReduceOp.SUM if op is None else op
+    if staged_through_host(tensor, group):
+        h = tensor.detach().cpu()
+        tdist.all_reduce(h, op=op, group=group)
+        tensor.copy_(h)
+    else:
+        tdist.all_reduce(tensor, op=op, group=group)
+    return tensor
+
+
+def broadcast_(tensor: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    if staged_through_host(tensor, group):
+        h = tensor.detach().cpu()
+        tdist.broadcast(h, src=src, group=group)
+        tensor.copy_(h)
+    else:
+        tdist.broadcast(tensor, src=src, group=group)
+    return tensor
+
+
 def reduce_loss(tensor: torch.Tensor, rank: int, world_size: int) -> None:
     """``main.py:16-20``: SUM-reduce to rank 0, rank 0 divides by world size.
 
@@ -200,7 +233,13 @@ def reduce_loss(tensor: torch.Tensor, rank: int, world_size: int) -> None:
     """
     with torch.no_grad():
         if is_initialized() and world_size > 1:
-            tdist.reduce(tensor, dst=0)
+            if staged_through_host(tensor):
+                h = tensor.detach().cpu()
+                tdist.reduce(h, dst=0)
+                if rank == 0:  # (the other ranks keep their local loss, as with the device path)
+                    tensor.copy_(h)
+            else:
+                tdist.reduce(tensor, dst=0)
         if rank == 0:
             tensor /= world_size
 
@@ -208,6 +247,6 @@ def reduce_loss(tensor: torch.Tensor, rank: int, world_size: int) -> None:
 def all_reduce_mean_(tensor: torch.Tensor) -> torch.Tensor:
     """Mean over ranks, in place (used by the synchronised metrics path)."""
     if is_initialized() and get_world_size() > 1:
-        tdist.all_reduce(tensor)
+        all_reduce_(tensor)
         tensor /= get_world_size()
     return tensor

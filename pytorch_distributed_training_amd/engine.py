@@ -239,9 +239,7 @@ class Engine:
             cnt[0] += (out.argmax(1) == labels).sum()
             cnt[1] += labels.numel()
         if pdist.is_initialized() and self.world_size > 1:
-            import torch.distributed as tdist
-
             cnt = cnt.float() if self.device.type == "cuda" else cnt
-            tdist.all_reduce(cnt)
+            pdist.all_reduce_(cnt)
         self.net.train()
         return float(cnt[0].item() / max(cnt[1].item(), 1.0))

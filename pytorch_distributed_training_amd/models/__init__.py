@@ -1,10 +1,11 @@
 """Model zoo (reference ``main.py:40`` uses ResNet-50; BASELINE.json adds the rest)."""
 from .resnet import ResNet, resnet18, resnet34, resnet50, resnet101, resnet152
-from .vit import VisionTransformer, vit_b_16, vit_tiny_test
+from .vit import VisionTransformer, vit_b_16, vit_l_16, vit_s_16, vit_ti_16, vit_tiny_test
 
 _REGISTRY = {
     "resnet18": resnet18, "resnet34": resnet34, "resnet50": resnet50, "resnet101": resnet101,
-    "resnet152": resnet152, "vit_b_16": vit_b_16, "vit_tiny_test": vit_tiny_test,
+    "resnet152": resnet152, "vit_b_16": vit_b_16, "vit_ti_16": vit_ti_16, "vit_s_16": vit_s_16,
+    "vit_l_16": vit_l_16, "vit_tiny_test": vit_tiny_test,
 }
 
 

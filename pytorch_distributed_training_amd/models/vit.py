@@ -122,6 +122,22 @@ def vit_b_16(num_classes=1000, image_size=224, **kw):
     return VisionTransformer(image_size, 16, 12, 12, 768, 3072, num_classes, **kw)
 
 
+def vit_ti_16(num_classes=1000, image_size=224, **kw):
+    """ViT-Tiny/16: width 192, 3 heads of 64."""
+    return VisionTransformer(image_size, 16, 12, 3, 192, 768, num_classes, **kw)
+
+
+def vit_s_16(num_classes=1000, image_size=224, **kw):
+    """ViT-Small/16: width 384, 6 heads of 64."""
+    return VisionTransformer(image_size, 16, 12, 6, 384, 1536, num_classes, **kw)
+
+
+def vit_l_16(num_classes=1000, image_size=224, **kw):
+    """ViT-Large/16 (torchvision ``vit_l_16`` keys): 24 layers, width 1024, 16 heads of 64."""
+    return VisionTransformer(image_size, 16, 24, 16, 1024, 4096, num_classes, **kw)
+
+
 def vit_tiny_test(num_classes=10, image_size=32, **kw):
-    """A 2-layer toy of the same architecture for CPU tests."""
-    return VisionTransformer(image_size, 8, 2, 2, 32, 64, num_classes, **kw)
+    """A 2-layer toy of the same architecture for CPU tests: width 32, ONE head of 32 (the smallest head the fused
+    attention kernels take, so that the toy runs without an oracle op on a GPU too)."""
+    return VisionTransformer(image_size, 8, 2, 1, 32, 64, num_classes, **kw)

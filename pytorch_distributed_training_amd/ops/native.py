@@ -217,15 +217,14 @@ def bn_bwd_elemt2(dz, z, xa, mean_a, invstd_a, gamma_a, psums_a, xb, mean_b, inv
 def attention_unsupported_reason(qkv, heads: int):
     if qkv.dtype != _BF16:
         return f"dtype {qkv.dtype} (native attention is bf16)"
-    if qkv.dim() != 3 or qkv.shape[2] != 3 * heads * 64:
-        return f"head_dim {qkv.shape[-1] // (3 * heads)} (native attention is head_dim 64)"
-    if qkv.shape[1] > 256:
-        return f"sequence length {qkv.shape[1]} > 256"
+    if qkv.dim() != 3 or qkv.shape[2] % (3 * heads) or qkv.shape[2] // (3 * heads) not in (32, 64, 128):
+        return f"head_dim {qkv.shape[-1] / (3 * heads):g} (native attention: head_dim 32, 64 or 128)"
     return None
 
 
 def attention_fwd(qkv, heads: int):
-    """packed qkv [B, S, 3*H*64] -> (out [B, S, H*64], lse [B, H, S]); softmax scale 1/sqrt(64)"""
+    """packed qkv [B, S, 3*H*hd] -> (out [B, S, H*hd], lse [B, H, S]); softmax scale 1/sqrt(hd), hd in {32, 64, 128};
+    whole-head kernels for hd 64 up to 256 tokens, block-streaming kernels for everything else (any length)"""
     return _C.attention_fwd(qkv.contiguous(), heads)
 
 
@@ -237,8 +236,8 @@ def attention_bwd(dout, qkv, out, lse, heads: int):
 def layernorm_unsupported_reason(x):
     if x.dtype != _BF16:
         return f"dtype {x.dtype} (native LayerNorm is bf16)"
-    if x.shape[-1] not in (256, 512, 768, 1024, 1280):
-        return f"width {x.shape[-1]}"
+    if x.shape[-1] % 4 or x.shape[-1] > 2048:
+        return f"width {x.shape[-1]} (native LayerNorm: multiples of 4 up to 2048)"
     return None
 
 

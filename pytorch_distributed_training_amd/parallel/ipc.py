@@ -115,12 +115,7 @@ class IpcSmallAllReduce:
         self.native = None
 
     def _group_all_reduce(self, t: torch.Tensor) -> None:
-        if t.is_cuda and tdist.get_backend(self.group) == "gloo":  # (tests: a CPU group driving GPU mailboxes)
-            c = t.cpu()
-            tdist.all_reduce(c, group=self.group)
-            t.copy_(c)
-        else:
-            tdist.all_reduce(t, group=self.group)
+        _all_reduce_group(t, self.group)  # (host-staged under gloo: tests drive GPU mailboxes from a CPU group)
 
     # -- collective self-check + timing --------------------------------------------------------------
     def validate(self, sizes=(132, 1028, 4100), iters: int = 20, check_timeout_s: float = 5.0):
@@ -191,12 +186,11 @@ def _decide(group, device):
         info["why"] = "selected" if device.type == "cuda" else "cpu tensors"
         return None, info
     if mode == "auto" and tdist.get_backend(group) != "nccl":
-        # GPU tensors under a gloo group (the one-GPU rehearsal of W > 1).  gloo moves a GPU tensor through the
-        # host and makes the compute stream wait for the copy back from one of ITS threads, in the middle of
-        # backward; together with kernels that wait for a peer on the same stream that closes a cycle
-        # (observed: two ranks sharing a GPU stop in the first backward).  RCCL keeps every dependency on the
-        # device and the reducer lets the compute stream wait for it only after backward, so the IPC path is
-        # for RCCL jobs; PDT_SYNCBN_COMM=ipc still forces it.
+        # GPU tensors under a gloo group (the one-GPU rehearsal of W > 1).  Such a job stages every collective
+        # through the host itself (dist.staged_through_host; profiles/r3_w2_hang.md has the stall that c10d's own
+        # gloo staging ran into and what it depends on) and the host-staged path is the one to rehearse there.  The
+        # IPC kernels are for RCCL jobs, where every dependency stays on the device; PDT_SYNCBN_COMM=ipc still
+        # forces them.
         info["why"] = "the group is not an RCCL group"
         return None, info
     ipc = IpcSmallAllReduce(group, device)
@@ -230,6 +224,12 @@ _TRACE = os.environ.get("PDT_TRACE_COLL", "0") == "1"  # one stderr line per sma
 _trace_n = 0
 
 
+def _all_reduce_group(t: torch.Tensor, group) -> None:
+    from ..dist import all_reduce_  # host-staged for GPU tensors on a gloo group (dist.staged_through_host)
+
+    all_reduce_(t, group=group)
+
+
 def small_all_reduce(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM of a small fp32 vector over ``group`` on the current stream."""
     global _trace_n
@@ -240,10 +240,10 @@ def small_all_reduce(t: torch.Tensor, group=None) -> torch.Tensor:
         _trace_n += 1
         r = tdist.get_rank()
         print(f"[coll r{r} {time.monotonic():.4f}] small#{_trace_n} n={t.numel()} issue", file=sys.stderr, flush=True)
-        tdist.all_reduce(t, group=group)
+        _all_reduce_group(t, group)
         print(f"[coll r{r} {time.monotonic():.4f}] small#{_trace_n} done", file=sys.stderr, flush=True)
     else:
-        tdist.all_reduce(t, group=group)
+        _all_reduce_group(t, group)
     return t
 
 

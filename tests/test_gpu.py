@@ -4,6 +4,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import pytest
 import torch
@@ -160,7 +161,44 @@ def test_attention_kernels(kc, shape):
     _assert_all_ok(kc, n)
 
 
-@pytest.mark.parametrize("shape", [(5, 768), (592, 256), (1030, 1024), (8 * 197, 768)])
+@pytest.mark.parametrize("shape", [(2, 257, 2, 64), (1, 577, 3, 64), (2, 300, 2, 32), (3, 65, 1, 32), (1, 1000, 2, 128),
+                                   (2, 197, 2, 128), (70, 130, 1000, 32)])
+def test_attention_block_streaming_kernels(kc, shape):
+    """Any sequence length, head_dim 32 / 64 / 128: the key-/query-block kernels (beyond 256 tokens, or a head size the
+    whole-head kernels are not built for); the last case cuts the batch (more than 65535 (batch, head) pairs)."""
+    n = len(kc.RESULTS)
+    b, s_, h, hd = shape
+    kc.check_attention(b, s_, h, False, hd=hd)
+    _assert_all_ok(kc, n)
+
+
+def test_attention_block_streaming_equals_whole_head_kernels():
+    """The two kernel families on the flagship shape (197 tokens, head_dim 64): same outputs and gradients to bf16
+    rounding (PDT_ATTN_GENERIC=1 is read once per process, so the forced run is a child process)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import torch, sys; sys.path.insert(0, %r)\n"
+        "from pytorch_distributed_training_amd.ops import native\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "qkv = torch.randn(4, 197, 3 * 4 * 64, generator=g).cuda().bfloat16()\n"
+        "do = torch.randn(4, 197, 4 * 64, generator=g).cuda().bfloat16()\n"
+        "o, l = native.attention_fwd(qkv, 4); d = native.attention_bwd(do, qkv, o, l, 4)\n"
+        "torch.save({'o': o.cpu(), 'l': l.cpu(), 'd': d.cpu()}, sys.argv[1])\n" % ROOT)
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (("whole", {}), ("stream", {"PDT_ATTN_GENERIC": "1"})):
+            f = os.path.join(td, tag + ".pt")
+            subprocess.run([sys.executable, "-c", code, f], check=True, env={**os.environ, **env}, timeout=300)
+            outs[tag] = torch.load(f, weights_only=True)
+    for k, tol in (("o", 2e-2), ("l", 1e-3), ("d", 3e-2)):
+        a, b = outs["whole"][k].float(), outs["stream"][k].float()
+        assert ((a - b).abs().max() / a.abs().max().clamp_min(1e-6)) < tol, k
+
+
+@pytest.mark.parametrize("shape", [(5, 768), (592, 256), (1030, 1024), (8 * 197, 768), (77, 32), (300, 192), (129, 384),
+                                   (64, 1536), (33, 2048), (10, 100)])
 def test_layernorm_kernels(kc, shape):
     n = len(kc.RESULTS)
     kc.check_layernorm(*shape, False)
@@ -642,7 +680,39 @@ def test_toy_transformer_widths_stay_on_the_native_gemm():
     losses = [float(eng.train_step(x, y)) for _ in range(10)]
     assert all(l == l for l in losses) and losses[-1] < losses[0] - 0.3, losses
     new = {k: v - before.get(k, 0) for k, v in pF.fallback_counts.items() if v != before.get(k, 0)}
-    assert not any(k.startswith(("linear", "mlp_gelu")) for k in new), new  # (head_dim 16 attention is the oracle's)
+    assert not new, new  # (one head of 32, width 32: attention, LayerNorm and every GEMM on the HIP kernels)
+
+
+@pytest.mark.parametrize("syncbn_comm,port", [("auto", "29641"), ("ipc", "29642")])
+def test_two_engine_ranks_on_one_gpu_train_to_identical_replicas(tmp_path, syncbn_comm, port):
+    """W = 2 with a GPU under every rank, as far as a one-GPU box allows: two engine processes share GPU 0 behind a
+    gloo group (RCCL refuses two ranks on one device).  The full step runs: HIP kernels, the C++ reducer with several
+    buckets in flight (rebuilt after step 1), SyncBatchNorm statistics through the group ("auto": host-staged, the path
+    a gloo job takes) or inside the BN kernels over IPC mailboxes ("ipc": the path an RCCL job on one host takes),
+    reduce_loss, the replica check.  This configuration used to stall in step 2 (profiles/r3_w2_hang.md); each rank
+    has a deadline and reports where it stands if it comes back."""
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PDT_TEST_DEADLINE_S="100", PDT_SYNCBN_COMM=syncbn_comm, PDT_QUIET="1")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "bench", "micro", "engine_w2_worker.py")],
+                                      env=env, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=150)
+            assert p.returncode == 0, se[-3000:]
+            outs.append(json.loads(so.strip().splitlines()[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    outs.sort(key=lambda o: o["rank"])
+    assert [o["world"] for o in outs] == [2, 2] and all(o["reducer"] == "native" for o in outs), outs
+    assert all(o["sync_bn_comm"]["path"] == ("ipc" if syncbn_comm == "ipc" else "group") for o in outs), outs
+    l0 = outs[0]["losses"]  # rank 0 holds the mean over the ranks (reduce_loss)
+    assert all(v == v for v in l0) and l0[-1] < 0.5 * l0[0], l0
+    assert outs[0]["bn_mean0"] == outs[1]["bn_mean0"], outs  # running statistics: same bits on both ranks
 
 
 def test_loader_sends_uint8_batches_and_the_cast_kernel_matches_the_fp32_path():
