@@ -683,6 +683,35 @@ def test_toy_transformer_widths_stay_on_the_native_gemm():
     assert not new, new  # (one head of 32, width 32: attention, LayerNorm and every GEMM on the HIP kernels)
 
 
+def _convergence_run(backend, extra_env, extra_args, td):
+    args = ["--model", "resnet18", "--image_size", "64", "--num_classes", "100", "--batch_size", "64", "--steps", "80",
+            "--window", "10", "--eval_batches", "8", "--noise", "0.4", "--seed", "0"]
+    r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "bench", "convergence.py"), "--backend", backend] + args +
+                       extra_args, env={**os.environ, **extra_env, "PDT_QUIET": "1"}, cwd=td, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_native_bf16_training_follows_the_fp32_oracle_loss_curve(tmp_path):
+    """Whole-system learning check the driver sees (bench/convergence.py, short form): ResNet-18 + SyncBN modules, Adam
+    lr 1e-3 (the reference's optimizer, /root/reference/main.py:79-80,100-104) on learnable synthetic images, the same
+    initial weights and sample stream through (a) the HIP kernels in bf16, (b) the fp32 PyTorch oracle ops, (c) the HIP
+    kernels replayed from a hipGraph with bf16 gradient buckets.  Every window of 10 steps of (a) and (c) must sit
+    within 0.05 + 15 % of the oracle's window (three seeds of this configuration differ by more than that among
+    themselves: profiles/r3_convergence_short.md), the loss must fall by 10x, and held-out accuracy must match."""
+    nat = _convergence_run("native", {}, [], tmp_path)
+    ora = _convergence_run("oracle", {"PDT_FORCE_REFERENCE_OPS": "1"}, [], tmp_path)
+    gra = _convergence_run("native", {}, ["--graph", "1", "--grad_dtype", "bf16"], tmp_path)
+    assert nat["dtype"] == "bf16" and ora["dtype"] == "fp32" and gra["graph"] is True, (nat, ora, gra)
+    for run in (nat, gra):
+        assert run["finite"] and len(run["loss_curve"]) == len(ora["loss_curve"]) == 8, run
+        for a, b in zip(run["loss_curve"], ora["loss_curve"]):
+            assert abs(a - b) <= 0.05 + 0.15 * b, (run["loss_curve"], ora["loss_curve"])
+        assert run["loss_curve"][-1] < 0.1 * run["loss_curve"][0], run
+        assert run["eval_top1"] >= ora["eval_top1"] - 0.03 and run["eval_top1"] > 0.9, (run, ora)
+
+
 @pytest.mark.parametrize("syncbn_comm,port", [("auto", "29641"), ("ipc", "29642")])
 def test_two_engine_ranks_on_one_gpu_train_to_identical_replicas(tmp_path, syncbn_comm, port):
     """W = 2 with a GPU under every rank, as far as a one-GPU box allows: two engine processes share GPU 0 behind a
