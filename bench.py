@@ -56,12 +56,16 @@ def main(argv=None) -> int:
     ap.add_argument("--sync_bn", action="store_true")
     ap.add_argument("--bucket_cap_mb", type=lambda v: v if v == "auto" else float(v), default=None)
     ap.add_argument("--grad_dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient buckets")
+    ap.add_argument("--grad_comm", default=None, choices=["rccl", "ipc", "auto"],
+                    help="gradient buckets through ncclAllReduce (default), the two-shot IPC kernel, or the faster of the two")
     ap.add_argument("--backend", default=None)
     ap.add_argument("--device", default=None, choices=["auto", "cuda", "cpu"],
                     help="with --backend gloo: cuda keeps the tensors on the GPU (several ranks may share one)")
     ap.add_argument("--reducer", default=None)
     ap.add_argument("--graph", action="store_true", help="capture the steady-state step in one hipGraph")
     args = ap.parse_args(argv)
+    if args.grad_comm is not None:
+        os.environ["PDT_GRAD_COMM"] = args.grad_comm  # (read when the reducer is built)
     # stdout carries exactly ONE line, the JSON result: everything else this process or its libraries print
     # (RCCL's version banner, c10d notices) goes to stderr for the duration of the run
     sys.stdout.flush()
@@ -162,7 +166,8 @@ def main(argv=None) -> int:
                 "image_size": args.image_size, "seq_len": None, "parallelism": f"dp{n}",
                 "optimizer": args.optimizer, "sync_bn": bool(args.sync_bn), "reducer": engine.net.reducer_kind,
                 "backend": env.backend, "baseline_images_per_sec": round(base, 1),
-                "library_fallbacks": dict(pF.fallback_counts), "final_loss": final_loss,
+                "library_fallbacks": dict(pF.fallback_counts),
+                "grad_comm": getattr(engine.net.reducer, "bucket_comm", None), "final_loss": final_loss,
                 "hip_graph": bool(engine._graph is not None), "batch_model": batch_model, "bucket_autotune": engine.net.bucket_autotune,
                 "priming_steps": priming,
                 # True: every bucket went through ncclAllReduce on the own communicator (also at N = 1)

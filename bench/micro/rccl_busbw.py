@@ -66,9 +66,43 @@ def worker(a) -> int:
         algbw = n * 4 / sec / 1e9
         rows.append({"mb": round(mb, 4), "us": round(sec * 1e6, 2), "algbw_GBps": round(algbw, 3),
                      "busbw_GBps": round(algbw * 2 * (world - 1) / max(world, 1), 3)})
+    ipc_rows = None
+    if a.ipc and dev.type == "cuda" and world > 1:
+        # the framework's own two-shot direct all-reduce over IPC windows (csrc/comm/ipc_allreduce.hip) on the same sizes:
+        # PDT_GRAD_COMM=auto makes this comparison at start-up per job; here it is a table
+        sys.path.insert(0, ROOT)
+        from pytorch_distributed_training_amd.parallel.ipc import IpcBucketAllReduce
+
+        red = IpcBucketAllReduce(None, dev, int(max(a.sizes_mb) * (1 << 20)))
+        if red.ok:
+            ipc_rows = []
+            for mb in [4.0 / 1024] + list(a.sizes_mb):
+                n = max(2, int(mb * (1 << 20)) // 4)
+                t = torch.ones(n, dtype=torch.float32, device=dev)
+                for _ in range(a.warmup):
+                    red.all_reduce_(t)
+                sync()
+                dist.barrier()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(a.iters):
+                    red.all_reduce_(t)
+                sync()
+                dt = torch.tensor([(time.perf_counter() - t0) / a.iters], dtype=torch.float64, device=dev)
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                sec = float(dt.item())
+                algbw = n * 4 / sec / 1e9
+                ipc_rows.append({"mb": round(mb, 4), "us": round(sec * 1e6, 2), "algbw_GBps": round(algbw, 3),
+                                 "busbw_GBps": round(algbw * 2 * (world - 1) / max(world, 1), 3)})
+            sync()
+            dist.barrier()
+            red.close()
+        elif rank == 0:
+            print(f"two-shot IPC all-reduce unavailable: {red.error}", file=sys.stderr, flush=True)
     if rank == 0:
         print("RESULT " + json.dumps({"world": world, "algo": os.environ.get("NCCL_ALGO", "default"),
-                                      "proto": os.environ.get("NCCL_PROTO", "default"), "rows": rows}), flush=True)
+                                      "proto": os.environ.get("NCCL_PROTO", "default"), "rows": rows,
+                                      "two_shot_ipc_rows": ipc_rows}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     return 0
@@ -99,8 +133,8 @@ def launch(a) -> int:
             env["NCCL_PROTO"] = proto
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(a.port + i), os.path.abspath(__file__), "--worker",
-               "--backend", a.backend, "--device", a.device, "--iters", str(a.iters), "--warmup", str(a.warmup),
-               "--sizes_mb"] + [str(s) for s in a.sizes_mb]
+               "--backend", a.backend, "--device", a.device, "--iters", str(a.iters), "--warmup", str(a.warmup)] + \
+              (["--ipc"] if (a.ipc and i == 0) else []) + ["--sizes_mb"] + [str(s) for s in a.sizes_mb]
         try:
             out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=a.timeout)
         except subprocess.TimeoutExpired:
@@ -118,7 +152,11 @@ def launch(a) -> int:
             continue
         print(f"{r['algo']:>8} {r['proto']:>8} " + " ".join(f"{row['busbw_GBps']:>12.1f}" for row in r["rows"][1:])
               + f"   {r['rows'][0]['us']:8.1f}")
+    ipc = next((r["two_shot_ipc_rows"] for r in results if r.get("two_shot_ipc_rows")), None)
+    if ipc:
+        print(f"{'two-shot':>8} {'ipc':>8} " + " ".join(f"{row['busbw_GBps']:>12.1f}" for row in ipc[1:]) + f"   {ipc[0]['us']:8.1f}")
     doc = summarize(results)
+    doc["two_shot_ipc_rows"] = ipc
     text = json.dumps(doc)
     print(text)
     if a.out:
@@ -140,6 +178,7 @@ def main() -> int:
     ap.add_argument("--port", type=int, default=29710)
     ap.add_argument("--timeout", type=int, default=300)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--ipc", action="store_true", help="also time the framework's two-shot direct all-reduce over IPC windows")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     return worker(a) if a.worker else launch(a)

@@ -1,0 +1,8 @@
+#!/bin/bash
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd $R && mkdir -p gpurun_out/r3 && export PYTHONPATH=$R
+timeout -k 10 600 python -u -m pytest tests/test_gpu.py -m gpu -x -q --timeout 300 --timeout-method thread -k "two_shot or two_engine_ranks" > gpurun_out/r3/pytest_ipc2.log 2>&1
+rc=$?; tail -30 gpurun_out/r3/pytest_ipc2.log | cut -c1-600; [ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python -u bench/micro/eager_host_profile.py > gpurun_out/r3/eager_host_profile.log 2>&1 || { tail -20 gpurun_out/r3/eager_host_profile.log; exit 1; }
+head -60 gpurun_out/r3/eager_host_profile.log

@@ -56,6 +56,9 @@ def get_parser() -> argparse.ArgumentParser:
     p.add_argument("--data_root", default="dataset", type=str)
     p.add_argument("--dataset_len", default=None, type=int, help="override the dataset length (synthetic sets)")
     p.add_argument("--num_classes", default=1000, type=int, help="width of the classifier head (reference: 1000)")
+    p.add_argument("--grad_comm", default=None, choices=["rccl", "ipc", "auto"],
+                   help="gradient buckets: the communicator's ncclAllReduce (default), the two-shot direct all-reduce over IPC "
+                        "windows, or whichever is faster on this job's links (timed at start-up); same as PDT_GRAD_COMM")
     p.add_argument("--optimizer", default="adam", choices=["adam", "adamw", "sgd"])
     p.add_argument("--momentum", default=0.9, type=float)
     p.add_argument("--weight_decay", default=0.0, type=float)
@@ -89,6 +92,8 @@ def get_parser() -> argparse.ArgumentParser:
 
 def main(argv=None) -> int:
     args = get_parser().parse_args(argv)
+    if args.grad_comm is not None:
+        os.environ["PDT_GRAD_COMM"] = args.grad_comm  # (read when the reducer is built)
     batch_size, job_id, epochs = args.batch_size, args.JobID, args.epochs
 
     env = pdist.init_process_group(backend=args.backend, init_method="env://", local_rank=args.local_rank)

@@ -81,7 +81,15 @@ PYBIND11_MODULE(_C, m) {
                         "IpcAllReduce takes a contiguous fp32 GPU tensor");
             hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
             c.all_reduce(t.data_ptr<float>(), t.numel(), cur);
-        });
+        })
+        // gradient buckets: two-shot direct all-reduce of a contiguous fp32 / bf16 GPU tensor on the current stream
+        .def("all_reduce_large_", [](pdt::IpcAllReduce& c, at::Tensor t) {
+            TORCH_CHECK(t.is_cuda() && t.is_contiguous() && (t.scalar_type() == at::kFloat || t.scalar_type() == at::kBFloat16),
+                        "IpcAllReduce.all_reduce_large_ takes a contiguous fp32 or bf16 GPU tensor");
+            hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
+            c.all_reduce_large(t.data_ptr(), t.numel(), t.scalar_type() == at::kBFloat16, cur);
+        })
+        .def_property_readonly("large_capacity_words", &pdt::IpcAllReduce::large_capacity_words);
 
     py::class_<pdt::Reducer, std::shared_ptr<pdt::Reducer>>(m, "Reducer")
         .def(py::init([](std::vector<at::Tensor> params, std::vector<std::string> names,
@@ -94,6 +102,8 @@ PYBIND11_MODULE(_C, m) {
              py::arg("params"), py::arg("names"), py::arg("rccl"), py::arg("process_group"), py::arg("world_size"),
              py::arg("bucket_cap_bytes"), py::arg("first_bucket_bytes"), py::arg("grad_dtype"),
              py::arg("gradient_as_bucket_view"))
+        .def("set_bucket_ipc", &pdt::Reducer::set_bucket_ipc)
+        .def("ipc_bucket_launches", &pdt::Reducer::ipc_bucket_launches)
         .def("prepare_for_backward", &pdt::Reducer::prepare_for_backward)
         .def("set_require_sync", &pdt::Reducer::set_require_sync)
         .def_property_readonly("rebuilt", &pdt::Reducer::rebuilt)

@@ -17,7 +17,7 @@ namespace pdt {
 IpcAllReduce::IpcAllReduce(int rank, int world, int device, int cap_elems, double timeout_s) : device_(device) {
     TORCH_CHECK(world >= 1 && world <= kIpcMaxRanks, "IpcAllReduce: world size ", world, " outside [1, ", kIpcMaxRanks, "]");
     TORCH_CHECK(rank >= 0 && rank < world, "IpcAllReduce: bad rank");
-    TORCH_CHECK(cap_elems > 0 && cap_elems <= (1 << 20), "IpcAllReduce: bad capacity");
+    TORCH_CHECK(cap_elems > 0 && cap_elems <= (1 << 26), "IpcAllReduce: bad capacity");
     PDT_HIP(hipSetDevice(device));
     mb_.rank = rank;
     mb_.world = world;
@@ -124,6 +124,27 @@ void IpcAllReduce::all_reduce(float* data, int64_t n, hipStream_t s) {
     static const bool debug = std::getenv("PDT_IPC_DEBUG") != nullptr;
     if (debug) fprintf(stderr, "[ipc rank %d] call %ld n=%ld stream=%p\n", mb_.rank, (long)++calls_, (long)n, (void*)s);
     launch_ipc_allreduce(data, (int)n, mb_, s);
+}
+
+void IpcAllReduce::all_reduce_large(void* data, int64_t numel, bool bf16, hipStream_t s) {
+    TORCH_CHECK(!closed_, "IpcAllReduce: closed");
+    TORCH_CHECK(ready_, "IpcAllReduce: open_peers() has not run");
+    TORCH_CHECK(!bf16 || numel % 2 == 0, "IpcAllReduce: a bf16 bucket needs an even element count");
+    TORCH_CHECK(reinterpret_cast<uintptr_t>(data) % 4 == 0, "IpcAllReduce: bucket not 4-byte aligned");
+    const int64_t nwords = bf16 ? numel / 2 : numel;
+    TORCH_CHECK(nwords >= 0 && nwords <= large_capacity_words(), "IpcAllReduce: bucket of ", nwords,
+                " words exceeds the windows (", large_capacity_words(), ")");
+    TORCH_CHECK(!timed_out(), "IpcAllReduce: an earlier all-reduce ran out of time waiting for a peer");
+    // enough workgroups to keep W-1 links busy, few enough to leave the CUs to backward (the kernel overlaps it)
+    static const int blocks = [] {
+        const char* e = std::getenv("PDT_IPC_BUCKET_BLOCKS");
+        const int b = e ? std::atoi(e) : 48;
+        return b < 1 ? 1 : (b > 256 ? 256 : b);
+    }();
+    const int64_t per_block = 2 * 512;
+    int64_t want = (nwords / mb_.world + per_block - 1) / per_block;
+    if (want < 1) want = 1;
+    launch_ipc_allreduce_large(data, (long)nwords, bf16, mb_, (int)(want < blocks ? want : blocks), s);
 }
 
 }  // namespace pdt

@@ -44,6 +44,9 @@ struct IpcMailboxes {
 
 // device launcher (ipc_allreduce.hip): in-place sum of n <= cap floats
 void launch_ipc_allreduce(float* data, int n, const IpcMailboxes& mb, hipStream_t s);
+// two-shot direct all-reduce of a bucket of 32-bit words (one fp32 or two bf16 each), in place; the window of every
+// rank holds [2][W][cap] words with cap >= ceil(nwords / W) rounded up to even (ipc_allreduce.hip has the protocol)
+void launch_ipc_allreduce_large(void* data, long nwords, bool bf16, const IpcMailboxes& mb, int blocks, hipStream_t s);
 
 class IpcAllReduce {
    public:
@@ -68,6 +71,10 @@ class IpcAllReduce {
     bool closed() const { return closed_; }
     void set_timeout(double seconds) { mb_.timeout_ticks = (long long)(seconds * 100e6); }
     void all_reduce(float* data, int64_t n, hipStream_t s);
+    // gradient buckets: two-shot direct all-reduce of `numel` fp32 or bf16 elements (bf16: an even count); an object
+    // used for this must not also carry small messages (the two protocols share the sequence word, not the layout)
+    void all_reduce_large(void* data, int64_t numel, bool bf16, hipStream_t s);
+    int64_t large_capacity_words() const { return (int64_t)mb_.world * (mb_.cap & ~1); }
     // for kernels that do the exchange themselves (ipc_device.h): the mailboxes, after the same checks as above
     const IpcMailboxes& mailboxes_for(int64_t n_elems);
 

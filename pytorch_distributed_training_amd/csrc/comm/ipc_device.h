@@ -68,6 +68,20 @@ __device__ __forceinline__ uint32_t ipc_wait_bits(const IpcMailboxes& mb, uint32
     }
     return (uint32_t)w;
 }
+// the same wait on an explicit word of the own window (two-shot bucket all-reduce)
+__device__ __forceinline__ uint32_t ipc_wait_word(const uint64_t* p, uint32_t seq, const IpcMailboxes& mb, bool* late,
+                                                  long long t0) {
+    uint64_t w = ipc_load_word(p);
+    while ((uint32_t)(w >> 32) != seq) {
+        if (*late || wall_clock64() - t0 > mb.timeout_ticks) {
+            *late = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        w = ipc_load_word(p);
+    }
+    return (uint32_t)w;
+}
 __device__ __forceinline__ float ipc_wait(const IpcMailboxes& mb, uint32_t seq, int sender, int i, bool* late,
                                           long long t0) {
     return __uint_as_float(ipc_wait_bits(mb, seq, sender, i, late, t0));

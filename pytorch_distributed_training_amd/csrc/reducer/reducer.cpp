@@ -123,6 +123,45 @@ Reducer::~Reducer() {
     remove_hooks();
     destroy_buckets();
     if (bwd_end_) hipEventDestroy(bwd_end_);
+    if (own_stream_) {
+        hipStreamSynchronize(own_stream_);
+        hipStreamDestroy(own_stream_);
+    }
+    if (own_ev_) hipEventDestroy(own_ev_);
+}
+
+void Reducer::set_bucket_ipc(std::shared_ptr<IpcAllReduce> ipc) {
+    std::lock_guard<std::mutex> g(mu_);
+    TORCH_CHECK(!callback_queued_, "set_bucket_ipc() must be called between iterations");
+    TORCH_CHECK(!ipc || is_cuda_, "set_bucket_ipc(): GPU parameters only");
+    TORCH_CHECK(!ipc || ipc->world_size() == world_, "set_bucket_ipc(): windows of ", ipc ? ipc->world_size() : 0,
+                " ranks for a job of ", world_);
+    ipc_ = std::move(ipc);
+    // Where the bucket kernels run.  Default: IN the compute stream.  Every rank then enqueues ONE sequence of kernels that
+    // wait for peers (SyncBN exchanges inside the BN kernels, bucket all-reduces), in the same order on every rank, so
+    // no cycle can form whatever the GPU co-schedules; the price is that a bucket's transfer (~0.2 ms for 16 MiB at
+    // W = 8 by the link model) is not hidden behind backward.  PDT_IPC_BUCKET_STREAM=comm puts them on the
+    // communicator's stream (or a stream of the reducer's own) to overlap backward, like ncclAllReduce: measured
+    // with two ranks SHARING one GPU, that variant stalled in 4 of 6 runs next to the in-kernel SyncBN exchange
+    // (two streams per process full of spinning waves on one device; profiles/r3_w2_hang.md), so it is opt-in.
+    const char* where = std::getenv("PDT_IPC_BUCKET_STREAM");
+    ipc_inline_ = !(where && std::string(where) == "comm");
+    if (ipc_ && !rccl_ && !own_stream_ && !ipc_inline_) {
+        int lo = 0, hi = 0;
+        PDT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const char* pr = std::getenv("PDT_IPC_BUCKET_PRIO");
+        PDT_HIP(hipStreamCreateWithPriority(&own_stream_, hipStreamNonBlocking, (pr && pr[0] == '0') ? lo : hi));
+        PDT_HIP(hipEventCreateWithFlags(&own_ev_, hipEventDisableTiming));
+    }
+}
+
+bool Reducer::ipc_fits(const Bucket& b) const {
+    if (!ipc_ || !is_cuda_ || world_ <= 1) return false;
+    const bool bf16 = grad_dtype_ == at::kBFloat16;
+    if (!bf16 && grad_dtype_ != at::kFloat) return false;
+    if (bf16 && b.plan.numel % 2 != 0) return false;
+    const int64_t words = bf16 ? b.plan.numel / 2 : b.plan.numel;
+    return words <= ipc_->large_capacity_words();
 }
 
 void Reducer::remove_hooks() {
@@ -252,7 +291,31 @@ void Reducer::launch(Bucket& b) {
     }
     if (!srcs.empty()) multi_flatten_tensors(srcs, dsts, scale);  // one launch: copy + 1/W (+ cast)  (N2)
 
-    if (rccl_ || pg_) {  // (a size-1 communicator is legal: the GPU tests use it to run this exact path)
+    if (ipc_fits(b)) {
+        // two-shot direct all-reduce over the peers' IPC windows: same stream discipline as the RCCL branch
+        hipStream_t compute = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(b.flat.device().index()).stream();
+        hipStream_t cs = ipc_inline_ ? compute : comm_stream();
+        if (ipc_inline_) {
+            // (the kernel sits in the compute stream itself: no overlap with backward, no second stream)
+        } else if (rccl_) {
+            rccl_->fence_from(compute);
+        } else {
+            PDT_HIP(hipEventRecord(own_ev_, compute));
+            PDT_HIP(hipStreamWaitEvent(own_stream_, own_ev_, 0));
+        }
+        if (timing_ && rccl_) {
+            if (!b.t0) {
+                PDT_HIP(hipEventCreate(&b.t0));
+                PDT_HIP(hipEventCreate(&b.t1));
+            }
+            PDT_HIP(hipEventRecord(b.t0, cs));
+        }
+        ipc_->all_reduce_large(b.flat.data_ptr(), b.plan.numel, grad_dtype_ == at::kBFloat16, cs);
+        if (timing_ && rccl_) PDT_HIP(hipEventRecord(b.t1, cs));
+        PDT_HIP(hipEventRecord(b.done, cs));
+        b.done_iter = iteration_;
+        ++ipc_launches_;
+    } else if (rccl_ || pg_) {  // (a size-1 communicator is legal: the GPU tests use it to run this exact path)
         if (rccl_ && is_cuda_) {
             hipStream_t compute = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(b.flat.device().index()).stream();
             rccl_->fence_from(compute);           // comm stream waits for the flatten
@@ -308,15 +371,16 @@ void Reducer::finalize() {
                     buckets_.size(), " buckets");
         ++debug_checks_;
     }
-    if (rccl_ || pg_) {
-        if (rccl_ && is_cuda_) {
+    if (rccl_ || pg_ || ipc_) {
+        if (device_comm()) {
             hipStream_t compute = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(params_[0].device().index()).stream();
             if (timing_) {  // where backward's own work ends: what the buckets finish after this is exposed
                 if (!bwd_end_) PDT_HIP(hipEventCreate(&bwd_end_));
                 PDT_HIP(hipEventRecord(bwd_end_, compute));
                 timed_ = true;
             }
-            for (auto& b : buckets_) PDT_HIP(hipStreamWaitEvent(compute, b.done, 0));
+            for (auto& b : buckets_)
+                if (b.done_iter == iteration_) PDT_HIP(hipStreamWaitEvent(compute, b.done, 0));
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             if (debug_ && hipStreamIsCapturing(compute, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
                 // event order: once the compute stream has drained, every all-reduce it waited for must be complete
@@ -326,7 +390,8 @@ void Reducer::finalize() {
                                 " all-reduce still pending after the compute stream waited for it");
                 ++debug_checks_;
             }
-        } else {
+        }
+        {
             for (auto& b : buckets_)
                 if (b.work) {
                     const size_t bidx = (size_t)(&b - buckets_.data());

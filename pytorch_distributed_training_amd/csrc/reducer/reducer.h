@@ -24,6 +24,7 @@
 #include <tuple>
 #include <vector>
 
+#include "../comm/ipc_allreduce.h"
 #include "../comm/rccl_comm.h"
 
 #include "bucket_plan.h"
@@ -37,6 +38,12 @@ class Reducer {
             c10::optional<at::ScalarType> grad_dtype, bool gradient_as_bucket_view);
     ~Reducer();
 
+    // Gradient buckets through the two-shot direct all-reduce over IPC windows (comm/ipc_allreduce.hip) instead of
+    // ncclAllReduce: in the compute stream by default, on the communicator's stream (or on a stream of the reducer's
+    // own when there is no RCCL communicator) with PDT_IPC_BUCKET_STREAM=comm; reducer.cpp says why.  Buckets that do
+    // not fit the windows keep the other path.
+    void set_bucket_ipc(std::shared_ptr<IpcAllReduce> ipc);
+    int64_t ipc_bucket_launches() const { std::lock_guard<std::mutex> g(mu_); return ipc_launches_; }
     void prepare_for_backward();
     void set_require_sync(bool v) { std::lock_guard<std::mutex> g(mu_); require_sync_ = v; }
     // (every getter takes the mutex: the autograd thread appends to these vectors while hooks fire; found by the
@@ -95,6 +102,14 @@ class Reducer {
     std::vector<at::Tensor> params_;
     std::vector<std::string> names_;
     std::shared_ptr<RcclComm> rccl_;
+    std::shared_ptr<IpcAllReduce> ipc_;      // optional: two-shot direct all-reduce of the buckets
+    hipStream_t own_stream_ = nullptr;       // ipc_ without rccl_: the stream the bucket kernels run on
+    hipEvent_t own_ev_ = nullptr;
+    int64_t ipc_launches_ = 0;
+    bool ipc_inline_ = true;                 // bucket kernels in the compute stream (PDT_IPC_BUCKET_STREAM=comm: side stream)
+    bool device_comm() const { return is_cuda_ && (rccl_ || ipc_); }  // completion = an event on a comm stream
+    hipStream_t comm_stream() const { return rccl_ ? rccl_->stream() : own_stream_; }
+    bool ipc_fits(const Bucket& b) const;
     c10::intrusive_ptr<c10d::ProcessGroup> pg_;
     int64_t world_;
     int64_t cap_, first_cap_;

@@ -247,6 +247,112 @@ def small_all_reduce(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
+# ------------------------------------------------------------------------------------------- gradient buckets
+class IpcBucketAllReduce(IpcSmallAllReduce):
+    """Windows for the two-shot direct all-reduce of gradient buckets (``csrc/comm/ipc_allreduce.hip``, SURVEY 5.8
+    layer 4): every rank stores shard j of its bucket straight into peer j's window (W-1 xGMI links at once), adds
+    the W versions of its own shard in rank order and stores the result into every peer's window.  ``bucket_bytes``
+    is the largest bucket it has to take; the windows cost 4x that per rank."""
+
+    def __init__(self, group, device, bucket_bytes: int, timeout_s: float | None = None):
+        world = tdist.get_world_size(group)
+        words = (int(bucket_bytes) + 3) // 4
+        cap = (words + world - 1) // world
+        cap += cap & 1
+        super().__init__(group, device, capacity=max(cap + 2, 1024), timeout_s=timeout_s)
+
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        self.native.all_reduce_large_(t)
+        return t
+
+    def validate(self, numel: int, iters: int = 5, check_timeout_s: float = 10.0):
+        """-> (error or None, ipc_ms, group_ms) on fp32 and bf16 buffers of ``numel`` elements (random data) against the
+        process group's all-reduce; collective, same discipline as :meth:`IpcSmallAllReduce.validate`."""
+        err = None
+
+        def note(msg):
+            nonlocal err
+            err = err or msg
+
+        self.native.set_timeout(check_timeout_s)
+        gen = torch.Generator().manual_seed(4321 + self.rank)
+        t_ipc = t_pg = float("inf")
+        numel -= numel % 2
+        for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2)):
+            for n in (2, 4098, numel):
+                x = torch.randn(n, generator=gen).to(self.device).to(dtype)
+                want = x.float().clone()
+                self._group_all_reduce(want)
+                got = None
+                for _ in range(2):
+                    got = x.clone()
+                    try:
+                        self.native.all_reduce_large_(got)
+                    except Exception as e:  # noqa: BLE001
+                        note(repr(e))
+                        break
+                torch.cuda.synchronize(self.device)
+                if self.native.timed_out():
+                    note("a peer did not arrive within the time limit")
+                if got is not None and err is None:
+                    scale = float(want.abs().max().clamp_min(1e-6))
+                    if not bool(((got.float() - want).abs().max() / scale) < tol):
+                        note(f"mismatch against the process group at n={n}, {dtype}")
+        if err is None:
+            x = torch.zeros(numel, device=self.device)
+            for which in ("ipc", "pg"):
+                fn = (lambda: self.native.all_reduce_large_(x)) if which == "ipc" else (lambda: self._group_all_reduce(x))
+                fn()
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    fn()
+                torch.cuda.synchronize(self.device)
+                dt = (time.perf_counter() - t0) / iters * 1e3
+                if which == "ipc":
+                    t_ipc = dt
+                else:
+                    t_pg = dt
+            if self.native.timed_out():
+                note("a peer did not arrive within the time limit")
+        err = self._agree(err)
+        if err is None:
+            self.native.set_timeout(self.timeout_s)
+        times = [(t_ipc, t_pg)] if self.rank == 0 else [None]
+        src = tdist.get_global_rank(self.group, 0) if self.group is not None else 0
+        tdist.broadcast_object_list(times, src=src, group=self.group)
+        return err, times[0][0], times[0][1]
+
+
+def bucket_all_reduce_path(group, device, bucket_bytes: int, mode: str | None = None):
+    """Which path the gradient buckets take (``PDT_GRAD_COMM``): ``rccl`` (default) = the communicator's
+    ``ncclAllReduce``; ``ipc`` = the two-shot direct kernel whenever its self-check against the process group
+    passes; ``auto`` = the same check, then whichever was faster on a buffer of one bucket (rank 0's clock decides, so
+    the job measures its own links at start-up).  -> ``(IpcBucketAllReduce or None, info dict)``; collective."""
+    mode = (mode or os.environ.get("PDT_GRAD_COMM", "rccl")).lower()
+    info = {"mode": mode, "path": "group", "why": None, "ipc_ms": None, "group_ms": None, "bucket_bytes": int(bucket_bytes)}
+    if mode not in ("ipc", "auto") or device.type != "cuda" or tdist.get_world_size(group) == 1:
+        info["why"] = "selected" if mode not in ("ipc", "auto") else "one rank / cpu tensors"
+        return None, info
+    ipc = IpcBucketAllReduce(group, device, bucket_bytes)
+    if not ipc.ok:
+        info["why"] = ipc.error
+        return None, info
+    err, t_ipc, t_pg = ipc.validate(int(bucket_bytes) // 4)
+    info["ipc_ms"], info["group_ms"] = t_ipc, t_pg
+    if err is not None:
+        info["why"] = err
+        ipc.close()
+        return None, info
+    if mode == "ipc" or t_ipc <= t_pg:
+        info["path"] = "ipc"
+        _paths[("bucket", id(group) if group is not None else None, str(device), id(ipc))] = (ipc, info)  # (close_all)
+        return ipc, info
+    info["why"] = "the process group was faster"
+    ipc.close()
+    return None, info
+
+
 def reset_paths() -> None:
     _paths.clear()
 

@@ -102,6 +102,22 @@ class NativeReducer:
         self._r = C.Reducer(self.params, names, self.rccl, pg, self.world, int(bucket_cap_bytes),
                             int(first_bucket_bytes), grad_dtype, bool(gradient_as_bucket_view))
         self._require_sync = True
+        # gradient buckets through the two-shot direct all-reduce over IPC windows instead of ncclAllReduce
+        # (PDT_GRAD_COMM=ipc|auto; default rccl: the kernel has run between two processes on one GPU, never across
+        # xGMI, and "auto" is the switch that lets a job measure both on its own links)
+        self.bucket_comm = {"mode": os.environ.get("PDT_GRAD_COMM", "rccl").lower(), "path": "group"}
+        self.bucket_ipc = None
+        if self.device.type == "cuda" and self.world > 1 and self.bucket_comm["mode"] in ("ipc", "auto"):
+            from .ipc import bucket_all_reduce_path
+
+            self.bucket_ipc, self.bucket_comm = bucket_all_reduce_path(process_group, self.device, int(bucket_cap_bytes))
+            if self.bucket_ipc is not None:
+                self._r.set_bucket_ipc(self.bucket_ipc.native)
+            if tdist.get_rank(process_group) == 0 and os.environ.get("PDT_QUIET", "0") == "0":
+                print(f"[grad-comm] {self.bucket_comm}", file=sys.stderr, flush=True)
+
+    def ipc_bucket_launches(self) -> int:
+        return int(self._r.ipc_bucket_launches())
 
     # -- same surface as PyReducer ------------------------------------------
     @property
@@ -171,6 +187,7 @@ class NativeReducer:
     def close(self) -> None:
         """Ordered teardown of this reducer's side of the job: hooks off, communicator drained and destroyed."""
         self._r.remove_hooks()
+        self._r.set_bucket_ipc(None)  # (the windows themselves are closed collectively: ipc.close_all in dist.shutdown)
         if self.rccl is not None:
             self.rccl.close()
 

@@ -712,18 +712,53 @@ def test_native_bf16_training_follows_the_fp32_oracle_loss_curve(tmp_path):
         assert run["eval_top1"] >= ora["eval_top1"] - 0.03 and run["eval_top1"] > 0.9, (run, ora)
 
 
-@pytest.mark.parametrize("syncbn_comm,port", [("auto", "29641"), ("ipc", "29642")])
-def test_two_engine_ranks_on_one_gpu_train_to_identical_replicas(tmp_path, syncbn_comm, port):
+@pytest.mark.parametrize("world,port", [(2, "29651"), (3, "29652")])
+def test_two_shot_direct_allreduce_over_ipc_windows(tmp_path, world, port):
+    """SURVEY 5.8 layer 4: the gradient-bucket all-reduce that uses every xGMI link at once (scatter shards into the
+    peers' windows, reduce in rank order, gather).  W processes share GPU 0 (the stores stay on the device instead of
+    crossing links; the protocol is the same): fp32 and bf16 buffers from 2 elements to 4 MiB against a CPU all-reduce,
+    identical bits on all ranks, exact rank-order sums, the start-up self-check, hipGraph replay, oversize refusal.
+    W = 3: shards that do not divide the buffer."""
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "tests", "ipc_bucket_worker.py")], env=env,
+                                      cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=200)
+            assert p.returncode == 0, se[-3000:]
+            outs.append(json.loads(so.strip().splitlines()[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for o in outs:
+        assert o["setup_error"] is None, o
+        assert o["worst_rel_err"]["fp32"] < 1e-6 and o["worst_rel_err"]["bf16"] < 1e-2 and o["same_bits"], o
+        assert o["rank_order_exact"], o
+        assert o["validate_error"] is None, o
+        assert all(v == [o["graph_want"]] * 4 for v in o["graph_vals"]), o
+        assert o["refused_oversize"], o
+
+
+@pytest.mark.parametrize("syncbn_comm,grad_comm,port", [("auto", "rccl", "29641"), ("ipc", "rccl", "29642"),
+                                                        ("ipc", "ipc", "29643")])
+def test_two_engine_ranks_on_one_gpu_train_to_identical_replicas(tmp_path, syncbn_comm, grad_comm, port):
     """W = 2 with a GPU under every rank, as far as a one-GPU box allows: two engine processes share GPU 0 behind a
     gloo group (RCCL refuses two ranks on one device).  The full step runs: HIP kernels, the C++ reducer with several
     buckets in flight (rebuilt after step 1), SyncBatchNorm statistics through the group ("auto": host-staged, the path
     a gloo job takes) or inside the BN kernels over IPC mailboxes ("ipc": the path an RCCL job on one host takes),
-    reduce_loss, the replica check.  This configuration used to stall in step 2 (profiles/r3_w2_hang.md); each rank
+    gradient buckets through the host-staged group ("rccl" here means "the group") or through the two-shot direct
+    all-reduce over IPC windows, in the compute stream ("ipc"), reduce_loss, the replica check.  This configuration used to stall in step 2 (profiles/r3_w2_hang.md); each rank
     has a deadline and reports where it stands if it comes back."""
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", PDT_TEST_DEADLINE_S="100", PDT_SYNCBN_COMM=syncbn_comm, PDT_QUIET="1")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PDT_TEST_DEADLINE_S="100", PDT_SYNCBN_COMM=syncbn_comm, PDT_QUIET="1",
+                   PDT_GRAD_COMM=grad_comm)
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "bench", "micro", "engine_w2_worker.py")],
                                       env=env, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -739,6 +774,10 @@ def test_two_engine_ranks_on_one_gpu_train_to_identical_replicas(tmp_path, syncb
     outs.sort(key=lambda o: o["rank"])
     assert [o["world"] for o in outs] == [2, 2] and all(o["reducer"] == "native" for o in outs), outs
     assert all(o["sync_bn_comm"]["path"] == ("ipc" if syncbn_comm == "ipc" else "group") for o in outs), outs
+    if grad_comm == "ipc":  # every bucket of every step went through the windows
+        assert all(o["grad_comm"]["path"] == "ipc" and o["ipc_bucket_launches"] >= 5 for o in outs), outs
+    else:
+        assert all(o["ipc_bucket_launches"] == 0 for o in outs), outs
     l0 = outs[0]["losses"]  # rank 0 holds the mean over the ranks (reduce_loss)
     assert all(v == v for v in l0) and l0[-1] < 0.5 * l0[0], l0
     assert outs[0]["bn_mean0"] == outs[1]["bn_mean0"], outs  # running statistics: same bits on both ranks
