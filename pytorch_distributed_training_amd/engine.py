@@ -72,15 +72,20 @@ class CapturedStep:
 
     def __init__(self, fn, inputs, stream: torch.cuda.Stream, ipc=None):
         self.inputs = tuple(inputs)
-        self.ipc = ipc
+        # one mailbox set or several (SyncBN statistics; the gradient buckets' windows under --grad_comm ipc)
+        self.ipcs = [i for i in (ipc if isinstance(ipc, (list, tuple)) else [ipc]) if i is not None]
+        self.ipc = self.ipcs[0] if self.ipcs else None
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=stream):
             self.output = fn(*self.inputs)
 
     def check_peers(self, when: str = "the previous replayed step") -> None:
-        if self.ipc is not None and self.ipc.timed_out():
-            raise RuntimeError(f"SyncBatchNorm exchange: a peer did not arrive within {self.ipc.timeout_s:.0f} s in "
-                               f"{when} (IPC mailbox status word set); its statistics are not to be trusted")
+        for ipc in self.ipcs:
+            if ipc.timed_out():
+                what = "gradient bucket all-reduce" if hasattr(ipc.native, "large_capacity_words") and \
+                    type(ipc).__name__ == "IpcBucketAllReduce" else "SyncBatchNorm exchange"
+                raise RuntimeError(f"{what}: a peer did not arrive within {ipc.timeout_s:.0f} s in {when} (IPC mailbox "
+                                   f"status word set); what it left behind is not to be trusted")
 
     def replay(self, *inputs):
         self.check_peers()
@@ -207,7 +212,8 @@ class Engine:
                 p.grad = None
             if hasattr(self.net.reducer, "rehook"):
                 self.net.reducer.rehook()
-        self._graph = CapturedStep(self._eager_step, (s_imgs, s_labels), self._capture_stream, self._ipc)
+        self._graph = CapturedStep(self._eager_step, (s_imgs, s_labels), self._capture_stream,
+                                   [self._ipc, getattr(self.net.reducer, "bucket_ipc", None)])
         self._graph_key = key
         # the capture pass enqueued nothing: run the step it recorded for this batch
         self._graph.graph.replay()

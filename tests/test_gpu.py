@@ -744,6 +744,43 @@ def test_two_shot_direct_allreduce_over_ipc_windows(tmp_path, world, port):
         assert o["refused_oversize"], o
 
 
+def _run_w2_pair(tmp_path, port, extra_env):
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PDT_TEST_DEADLINE_S="100", PDT_QUIET="1", **extra_env)
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "bench", "micro", "engine_w2_worker.py")],
+                                      env=env, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=150)
+            assert p.returncode == 0, se[-3000:]
+            outs.append(json.loads(so.strip().splitlines()[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return sorted(outs, key=lambda o: o["rank"])
+
+
+def test_two_ranks_captured_step_with_peer_exchanges_inside_equals_eager(tmp_path):
+    """A hipGraph of the WHOLE step at W = 2: the SyncBN exchanges inside the BN kernels and the gradient buckets through
+    the two-shot IPC all-reduce are all inside the captured launch sequence (no host-side collective in the step), on
+    two processes sharing GPU 0.  The replayed run must give the eager run's losses on every rank, step by step, and
+    bit-identical replicas (the ADVICE r2 condition for capturing at world size > 1: a captured step with at least two
+    ranks verified against eager)."""
+    common = {"PDT_SYNCBN_COMM": "ipc", "PDT_GRAD_COMM": "ipc", "PDT_TEST_STEPS": "8"}
+    eager = _run_w2_pair(tmp_path, "29645", {**common, "PDT_TEST_GRAPH": "0"})
+    graph = _run_w2_pair(tmp_path, "29646", {**common, "PDT_TEST_GRAPH": "1"})
+    assert all(o["hip_graph"] and o["graph_failed"] is None for o in graph), graph
+    assert not any(o["hip_graph"] for o in eager), eager
+    for e, g in zip(eager, graph):
+        assert g["losses"] == pytest.approx(e["losses"], rel=1e-5, abs=1e-6), (e["losses"], g["losses"])
+        assert g["ipc_bucket_launches"] >= 5 and g["sync_bn_comm"]["path"] == "ipc", g
+    assert graph[0]["bn_mean0"] == graph[1]["bn_mean0"] == eager[0]["bn_mean0"], (graph, eager)
+
+
 @pytest.mark.parametrize("syncbn_comm,grad_comm,port", [("auto", "rccl", "29641"), ("ipc", "rccl", "29642"),
                                                         ("ipc", "ipc", "29643")])
 def test_two_engine_ranks_on_one_gpu_train_to_identical_replicas(tmp_path, syncbn_comm, grad_comm, port):
