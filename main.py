@@ -117,21 +117,26 @@ def main(argv=None) -> int:
     timer = metrics.StepTimer()
 
     # CIFAR-shaped steps are ~550 kernels of a few microseconds: launch-bound, 1.7x faster replayed from a hipGraph.
-    # `auto` captures only in single-process runs: a captured multi-rank step (bucket all-reduces on the
-    # communicator's stream + BN kernels that wait on peers' mailboxes inside the graph) has only been rehearsed
-    # with a size-1 communicator and with two processes on ONE GPU, never on two GPUs, so it stays opt-in
-    # (`--graph`) until a node has run it; the eager W > 1 step goes through the fused C++ nodes instead.
-    use_graph = args.graph == "on" or (args.graph == "auto" and env.device.type == "cuda" and world_size == 1
-                                       and max(trainset.sample_shape[1:]) <= 64)
+    # `auto` captures (a) single-process runs and (b) multi-rank runs whose step has NO library collective inside: SyncBN
+    # statistics exchanged inside the BN kernels and gradient buckets through the two-shot IPC kernel (`--grad_comm
+    # ipc|auto` when it is chosen).  (b) is the combination that has been verified against eager with two ranks
+    # (tests/test_gpu.py::test_two_ranks_captured_step_with_peer_exchanges_inside_equals_eager); a captured step with
+    # ncclAllReduce inside has only run with a size-1 communicator, so it stays opt-in (`--graph`) until a node has
+    # run it.  Every replay is followed by a check of the IPC status words.
+    small = env.device.type == "cuda" and max(trainset.sample_shape[1:]) <= 64
+    use_graph = args.graph == "on" or (args.graph == "auto" and small and world_size == 1)
+    maybe_graph = args.graph == "auto" and small and world_size > 1
     with profiling.make_profiler(args.profile, job_id) as prof:
         engine = Engine(EngineConfig(
             model=args.model, num_classes=args.num_classes, dtype=args.dtype, optimizer=args.optimizer, lr=args.lr,
             momentum=args.momentum, weight_decay=args.weight_decay, sync_bn=args.sync_bn,
-            bucket_cap_mb=args.bucket_cap_mb, grad_dtype=args.grad_dtype, seed=args.seed, graph=use_graph,
+            bucket_cap_mb=args.bucket_cap_mb, grad_dtype=args.grad_dtype, seed=args.seed, graph=use_graph or maybe_graph,
             # the torch profiler's one cycle (wait 2 + warmup 2 + active 6) ends at step 10: capture after it, so
             # that the trace shows real kernels and no collection is active while the stream is being captured
             graph_warmup=12 if args.profile == "torch" else 3,
             image_size=trainset.sample_shape[1]))
+        if maybe_graph:
+            use_graph = engine.cfg.graph = engine.device_only_step()
         start_epoch, global_step, resume_batches = 0, 0, 0
         if args.resume:
             st = ckpt.load_checkpoint(args.resume, engine.net, engine.optimizer, sampler)

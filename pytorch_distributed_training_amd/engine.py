@@ -169,6 +169,15 @@ class Engine:
             self.net.assert_replicas_equal()  # raises on the first diverged step instead of training on garbage
         return loss
 
+    def device_only_step(self) -> bool:
+        """True when every cross-rank exchange of a training step runs inside this framework's own kernels (SyncBN
+        statistics inside the BN kernels, gradient buckets through the two-shot IPC all-reduce, no per-forward buffer
+        broadcast): the multi-rank configuration whose hipGraph capture is verified against eager."""
+        if self.world_size == 1:
+            return True
+        bn_ok = (not self.cfg.sync_bn) or self._ipc is not None
+        return bool(bn_ok and getattr(self.net.reducer, "bucket_ipc", None) is not None and not self.net.broadcast_buffers)
+
     def close(self) -> None:
         """Ordered teardown of the replica (call before ``dist.shutdown``)."""
         g, self._graph = self._graph, None
