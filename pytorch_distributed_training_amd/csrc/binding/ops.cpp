@@ -252,12 +252,19 @@ std::tuple<Tensor, Tensor> conv2d_fwd(const Tensor& x, const Tensor& w, int64_t 
 // bn_*: when given (stride 1 only), dx is the gradient w.r.t. the OUTPUT of a BN+ReLU with input bn_x / activity
 // mask bn_mask / statistics bn_mean, bn_invstd, and the second result holds the BN-backward partial sums
 // [P<=32, 2, Cin] computed in the epilogue (what bn_bwd_reduce would return for this dx).
-std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_shape, int64_t KH,
-                                        int64_t KW, int64_t stride, int64_t pad, const c10::optional<Tensor>& addend,
-                                        const c10::optional<Tensor>& bn_x, const c10::optional<Tensor>& bn_mask,
-                                        const c10::optional<Tensor>& bn_mean, const c10::optional<Tensor>& bn_invstd,
-                                        const c10::optional<Tensor>& addend_mask, int64_t addend_stride, int64_t cfg) {
+// bn2_*: a SECOND BatchNorm that receives this same dx through the same ReLU gate (bottleneck bn3 + the BatchNorm of
+// the downsample branch): when the launch goes to the GEMM core (pointwise, wide output) the third result holds that
+// BatchNorm's partial sums [P, 2, Cin] as well (row 0 = sum g, shared); otherwise it is undefined and the caller
+// reduces on its own.
+std::tuple<Tensor, Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std::vector<int64_t> x_shape, int64_t KH,
+                                                int64_t KW, int64_t stride, int64_t pad, const c10::optional<Tensor>& addend,
+                                                const c10::optional<Tensor>& bn_x, const c10::optional<Tensor>& bn_mask,
+                                                const c10::optional<Tensor>& bn_mean, const c10::optional<Tensor>& bn_invstd,
+                                                const c10::optional<Tensor>& addend_mask, int64_t addend_stride, int64_t cfg,
+                                                const c10::optional<Tensor>& bn2_x, const c10::optional<Tensor>& bn2_mean,
+                                                const c10::optional<Tensor>& bn2_invstd) {
     check_nhwc_bf16(dy, "dy");
+    const bool bnr2 = bn2_x.has_value() && bn2_x->defined();
     TORCH_CHECK(addend_stride == 1 || addend_stride == 2, "addend_stride must be 1 or 2");
     const bool bnr = bn_x.has_value() && bn_x->defined();
     const void* addend_ptr = nullptr;
@@ -327,7 +334,7 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
         launch_conv_win64(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), bnr ? slab.data_ptr<float>() : nullptr, (int)B, (int)H,
                           (int)W, 1, bx, bm, bmean, binv, s);
         if (bnr) psums = shrink_rows(slab, grid, 2 * C, kReduceChunks).view({-1, 2, C});
-        return {dx, psums};
+        return {dx, psums, Tensor()};
     }
     if (cfg == kCfgWin64) cfg = 0;  // (with an addend: implicit-GEMM kernel)
     const bool taps = conv_gemm_taps_ok(B, N, C, H, W, KH, KW, stride, pad, cfg);
@@ -373,9 +380,23 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
             slab = at::empty({m_tiles, 2 * C}, dy.options().dtype(at::kFloat));
             ga.stats_slab = slab.data_ptr<float>();
         }
+        Tensor psums2, slab2;
+        const bool dual = bnr && bnr2 && !taps;
+        if (dual) {
+            check_nhwc_bf16(*bn2_x, "bn2_x");
+            TORCH_CHECK(bn2_x->sizes().vec() == x_shape, "bn2_x must have the shape of dx");
+            TORCH_CHECK(bn2_mean.has_value() && bn2_invstd.has_value(), "bn2_mean / bn2_invstd missing");
+            check_vec_f32(*bn2_mean, C, "bn2_mean"); check_vec_f32(*bn2_invstd, C, "bn2_invstd");
+            ga.bnr_x2 = bn2_x->data_ptr();
+            ga.bnr_mean2 = bn2_mean->data_ptr<float>();
+            ga.bnr_invstd2 = bn2_invstd->data_ptr<float>();
+            slab2 = at::empty({m_tiles, 2 * C}, dy.options().dtype(at::kFloat));
+            ga.stats_slab2 = slab2.data_ptr<float>();
+        }
         launch_gemm_nt(ga, s);
         if (bnr) psums = shrink_rows(slab, m_tiles, 2 * C, kReduceChunks).view({-1, 2, C});
-        return {dx, psums};
+        if (dual) psums2 = shrink_rows(slab2, m_tiles, 2 * C, kReduceChunks).view({-1, 2, C});
+        return {dx, psums, psums2};
     }
     if (cfg == kCfgGemmCore) cfg = 0;  // (compact stride-2 addend: implicit-GEMM kernel only)
     const long dy_img = Ho * Wo * N * 2, dx_img = H * W * C * 2;
@@ -437,7 +458,7 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
             row += tiles[ci];
         }
         if (bnr) psums = shrink_rows(slab, m_tiles, 2 * C, kReduceChunks).view({-1, 2, C});
-        return {dx, psums};
+        return {dx, psums, Tensor()};
     }
     TORCH_CHECK(!bnr, "the fused BN-backward reduction is implemented for stride-1 data gradients");
     // stride 2: one launch per output parity class; a class without taps stays zero
@@ -471,7 +492,7 @@ std::tuple<Tensor, Tensor> conv2d_dgrad(const Tensor& dy, const Tensor& wt, std:
             launch_conv_igemm(at_image(dy.data_ptr(), b0, dy_img), wt.data_ptr(), at_image(dx.data_ptr(), b0, dx_img), gc,
                               nullptr, s, (int)cfg);
         }
-    return {dx, Tensor()};
+    return {dx, Tensor(), Tensor()};
 }
 
 bool wgrad_win_enabled() {
@@ -1538,7 +1559,9 @@ void bind_ops(pybind11::module& m) {
           pybind11::arg("kw"), pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("addend") = pybind11::none(),
           pybind11::arg("bn_x") = pybind11::none(), pybind11::arg("bn_mask") = pybind11::none(),
           pybind11::arg("bn_mean") = pybind11::none(), pybind11::arg("bn_invstd") = pybind11::none(),
-          pybind11::arg("addend_mask") = pybind11::none(), pybind11::arg("addend_stride") = 1, pybind11::arg("cfg") = 0);
+          pybind11::arg("addend_mask") = pybind11::none(), pybind11::arg("addend_stride") = 1, pybind11::arg("cfg") = 0,
+          pybind11::arg("bn2_x") = pybind11::none(), pybind11::arg("bn2_mean") = pybind11::none(),
+          pybind11::arg("bn2_invstd") = pybind11::none());
     m.def("conv2d_wgrad", &conv2d_wgrad, pybind11::arg("dy"), pybind11::arg("x"), pybind11::arg("kh"), pybind11::arg("kw"),
           pybind11::arg("stride"), pybind11::arg("pad"), pybind11::arg("splits") = 0);
     m.def("conv_stem_fwd", &conv_stem_fwd);

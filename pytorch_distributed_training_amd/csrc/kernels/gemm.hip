@@ -95,7 +95,9 @@ __device__ __forceinline__ int stage_off(int s) { return s ? STAGE1_OFF : 0; }
 // (3x3, stride 1, same-size output): tap (dh, dw) reads the A row of pixel (y + dh, x + dw), which is the SAME row
 // pattern shifted by (dh * W + dw) rows -- a per-tap constant that goes into the DMA's scalar offset -- and only the
 // zero padding is per lane: 9 validity bits per staged row, computed once per tile.
-template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV, bool TAPS>
+// DUAL (CONV == 2 only): a second BatchNorm takes the same gated gradient (kernels.h, bnr_x2): one more once-read operand
+// in the row pass and a third per-column sum; its own build so that the common one keeps its registers.
+template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV, bool TAPS, bool DUAL = false>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
         b_off[ks] = 2 * HALF_BYTES + (wc >> 1) * HALF_BYTES + (wc & 1) * 64 * 128 + lo;
     }
     const int och = tid & 31, orow = tid >> 5;  // store pass: 32 chunks of 8 columns per row, 16 rows per pass
-    constexpr int PB = CONV == 2 ? 4 : 8;       // passes whose global reads are in flight together
+    constexpr int PB = CONV == 2 ? (DUAL ? 2 : 4) : 8;  // passes whose global reads are in flight together
 
     // ---- prologue of the first tile: K-tile 0
     int gk = 0;  // K-tiles consumed so far: K-tile t of the current tile lives in stage (gk + t) & 1
@@ -317,11 +319,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                                                     use_extra ? (uint32_t)((long)orows_m * lde * 2) : 0u);
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(bnr ? static_cast<const char*>(a.bnr_x) + om0 * a.ldc * 2 : nullptr,
                                                     bnr ? (uint32_t)((long)orows_m * a.ldc * 2) : 0u);
+        const __amdgpu_buffer_rsrc_t rx2 = make_rsrc(DUAL ? static_cast<const char*>(a.bnr_x2) + om0 * a.ldc * 2 : nullptr,
+                                                     DUAL ? (uint32_t)((long)orows_m * a.ldc * 2) : 0u);
         // masks: one bit per element, [pixel][C/8] bytes (ldc == N for the convolution modes)
         const uint8_t* amask = has_amask ? a.addend_mask + ((om0 * a.ldc) >> 3) : nullptr;
         const uint8_t* bmask = bnr ? a.bnr_mask + ((om0 * a.ldc) >> 3) : nullptr;
         constexpr bool SUMS2 = CONV != 0;  // two per-column sums instead of one
         float csum[8], csq[SUMS2 ? 8 : 1], mu[CONV == 2 ? 8 : 1], is[CONV == 2 ? 8 : 1];
+        float csq2[DUAL ? 8 : 1], mu2[DUAL ? 8 : 1], is2[DUAL ? 8 : 1];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             csum[k] = 0.f;
@@ -329,6 +334,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
             if (CONV == 2) {
                 mu[k] = bnr && col_ok ? a.bnr_mean[ncol + k] : 0.f;
                 is[k] = bnr && col_ok ? a.bnr_invstd[ncol + k] : 0.f;
+            }
+            if (DUAL) {
+                csq2[k] = 0.f;
+                mu2[k] = col_ok ? a.bnr_mean2[ncol + k] : 0.f;
+                is2[k] = col_ok ? a.bnr_invstd2[ncol + k] : 0.f;
             }
         }
 
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
             // (masked ones are dropped by the descriptor's range check).
 #pragma unroll
             for (int pb = 0; pb < 8; pb += PB) {
-                bf16x8 ev[PB], bx[CONV == 2 ? PB : 1];
+                bf16x8 ev[PB], bx[CONV == 2 ? PB : 1], bx2[DUAL ? PB : 1];
                 unsigned abits[CONV == 2 ? PB : 1], bbits[CONV == 2 ? PB : 1];
                 uint32_t coff[PB];
 #pragma unroll
@@ -380,6 +390,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                             bbits[p] = 0u;
                             if (bnr) {
                                 bx[p] = buffer_load_bf16x8_stream(rx, eo);
+                                if (DUAL) bx2[p] = buffer_load_bf16x8_stream(rx2, eo);
                                 bbits[p] = in ? bmask[eo >> 4] : 0u;
                             }
                         }
@@ -428,6 +439,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                                 const float gg = ((bbits[p] >> k) & 1u) ? (float)v[k] : 0.f;
                                 csum[k] += gg;
                                 csq[k] += gg * ((float)bx[p][k] - mu[k]) * is[k];
+                                if (DUAL) csq2[k] += gg * ((float)bx2[p][k] - mu2[k]) * is2[k];
                             }
                         }
                     }
@@ -454,22 +466,30 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
             for (int k = 0; k < 8; ++k) {
                 csum[k] += __shfl_xor(csum[k], 32, 64);
                 if (SUMS2) csq[k] += __shfl_xor(csq[k], 32, 64);
+                if (DUAL) csq2[k] += __shfl_xor(csq2[k], 32, 64);
             }
             if (lane < 32) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     Ss[wave * BN + och * 8 + k] = csum[k];
                     if (SUMS2) Ss[(8 + wave) * BN + och * 8 + k] = csq[k];
+                    if (DUAL) Ss[(16 + wave) * BN + och * 8 + k] = csq2[k];
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (tid < BN && on0 + tid < a.N) {
-                float s = 0.f, q = 0.f;
+                float s = 0.f, q = 0.f, q2 = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
                     s += Ss[w * BN + tid];
                     if (SUMS2) q += Ss[(8 + w) * BN + tid];
+                    if (DUAL) q2 += Ss[(16 + w) * BN + tid];
+                }
+                if (DUAL) {  // same row layout as stats_slab: [sum g (shared), sum g * xhat2]
+                    float* dst2 = a.stats_slab2 + (long)otile_m * 2 * a.N;
+                    dst2[on0 + tid] = s;
+                    dst2[a.N + on0 + tid] = q2;
                 }
                 if (SUMS2) {
                     float* dst = a.stats_slab + (long)otile_m * 2 * a.N;
@@ -490,15 +510,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
 
 int gemm_m_tiles(long M) { return (int)((M + BM - 1) / BM); }
 
-template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV, bool TAPS = false>
+template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV, bool TAPS = false, bool DUAL = false>
 static void launch_variant(const GemmArgs& a, int grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV, TAPS>),
+        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV, TAPS, DUAL>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV, TAPS>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV, TAPS, DUAL>), dim3(grid), dim3(512), LDS_BYTES, s, a);
 }
 
 void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
@@ -534,7 +554,7 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
     if (a.ntaps > 0) {
         // spatial filter: dense NHWC rows, K = channels per tap (a multiple of the K-tile), taps in the weight rows
         const bool fused = a.addend || a.bnr_x;
-        if (ragged || extra || act || colsum || a.bias || a.ldc != a.N || a.lda != a.K || a.ntaps > 9 || a.H <= 0 ||
+        if (a.bnr_x2 || ragged || extra || act || colsum || a.bias || a.ldc != a.N || a.lda != a.K || a.ntaps > 9 || a.H <= 0 ||
             a.W <= 0 || a.W > 126 || a.M % ((long)a.H * a.W) != 0 || a.M >= (1L << 31) || (a.conv_mode == 1 && !a.stats_slab) ||
             (a.conv_mode == 2 && (!fused || (a.bnr_x && !(a.stats_slab && a.bnr_mask && a.bnr_mean && a.bnr_invstd)) ||
                                   (a.addend_mask && !a.addend))) ||
@@ -560,7 +580,12 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
             fprintf(stderr, "launch_gemm_nt: unsupported convolution epilogue\n");
             abort();
         }
+        if (a.bnr_x2 && !(a.conv_mode == 2 && a.bnr_x && a.bnr_mean2 && a.bnr_invstd2 && a.stats_slab2)) {
+            fprintf(stderr, "launch_gemm_nt: second BatchNorm operand without the first / its statistics\n");
+            abort();
+        }
         if (a.conv_mode == 1) launch_variant<0, false, false, false, 1>(a, grid, s);
+        else if (a.bnr_x2) launch_variant<0, false, false, false, 2, false, true>(a, grid, s);
         else launch_variant<0, false, false, false, 2>(a, grid, s);
         return;
     }

@@ -268,6 +268,12 @@ struct GemmArgs {
     const uint8_t* bnr_mask;     // [M][N/8]: activity of the ReLU behind that BatchNorm
     const float* bnr_mean;       // [N]
     const float* bnr_invstd;     // [N]
+    // mode 2, optional SECOND BatchNorm fed by the same gradient through the same ReLU gate (bottleneck bn3 + the BN of
+    // the downsample branch): stats_slab2 [m_tiles][2][N] receives (sum g, sum g * xhat2)
+    const void* bnr_x2;          // [M][N] bf16 or null
+    const float* bnr_mean2;      // [N]
+    const float* bnr_invstd2;    // [N]
+    float* stats_slab2;          // [m_tiles][2][N]
     // spatial filter as implicit GEMM (stride 1, output grid == input grid H x W, rows of A are pixels): K runs over
     // ntaps x (K / 64) tiles; tap t reads pixel (y + tap_dh, x + tap_dw) of the same image (zeros outside) and the
     // weight columns [tap_w * K, (tap_w + 1) * K) of B, whose rows are ldb = wtaps * K long.  ntaps == 0: plain GEMM.

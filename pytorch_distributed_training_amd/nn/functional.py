@@ -131,6 +131,10 @@ class _Conv2dFn(torch.autograd.Function):
                     sink.fulfil(dx, psums)
                 else:
                     dx = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, compact, addend_stride=2)
+            elif sink is not None and sink.second is not None and be is not reference:
+                dx, psums, psums2 = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, dskip, sink.operands(), gate,
+                                                    bn_sink2=sink.second)
+                sink.fulfil(dx, psums, psums2)
             elif sink is not None:
                 dx, psums = be.conv2d_dgrad(dy, wk, x_shape, stride, padding, dskip, sink.operands(), gate)
                 sink.fulfil(dx, psums)
@@ -203,14 +207,19 @@ class _BNSink:
     then skips its own reduction pass (one full read of dz and x per layer).  The BN only trusts the result when
     the gradient it receives is that very tensor."""
 
-    __slots__ = ("x", "mask", "mean", "invstd", "psums", "dz_ptr", "dz_version")
+    __slots__ = ("x", "mask", "mean", "invstd", "psums", "dz_ptr", "dz_version", "second", "psums2")
 
     def __init__(self):
         self.x = self.mask = self.mean = self.invstd = self.psums = None
         self.dz_ptr = self.dz_version = None
+        self.second = self.psums2 = None
 
     def arm(self, x, mask, mean, invstd):
         self.x, self.mask, self.mean, self.invstd = x, mask, mean, invstd
+
+    def arm_second(self, x2, mean2, invstd2):
+        """A second BN that receives the same gradient through the same gate (downsample BN next to bn3)."""
+        self.second = (x2, mean2, invstd2)
 
     def usable_for(self, z) -> bool:
         return self.x is not None and self.mask is not None and tuple(z.shape) == tuple(self.x.shape)
@@ -218,14 +227,22 @@ class _BNSink:
     def operands(self):
         return (self.x, self.mask, self.mean, self.invstd)
 
-    def fulfil(self, dz, psums) -> None:
+    def fulfil(self, dz, psums, psums2=None) -> None:
         self.psums, self.dz_ptr, self.dz_version = psums, dz.data_ptr(), dz._version
+        self.psums2 = psums2
 
     def take(self, dz):
-        """The fused partial sums if ``dz`` is the tensor they were computed from, else None."""
+        """The fused partial sums if ``dz`` is the tensor they were computed from, else None (``take2``: the second
+        BN's, call it first)."""
         ps = self.psums
         ok = ps is not None and dz.data_ptr() == self.dz_ptr and dz._version == self.dz_version
         self.x = self.mask = self.mean = self.invstd = self.psums = None  # drop the references either way
+        self.second = self.psums2 = None
+        return ps if ok else None
+
+    def take2(self, dz):
+        ps = self.psums2
+        ok = ps is not None and dz.data_ptr() == self.dz_ptr and dz._version == self.dz_version
         return ps if ok else None
 
 
@@ -333,6 +350,10 @@ class _BNActFn(torch.autograd.Function):
         if sink is not None and relu and be is not reference and act is not None and act.dtype == torch.uint8:
             sink.arm(x, act, mean, invstd)
             ctx.sink = sink
+            pend = ctx.res_pend
+            if (_FUSE_DUAL_SUMS and DUAL_BN_BACKWARD and pend is not None and pend.owner is not None and cfg.training
+                    and pend.owner[0].shape == x.shape and pend.owner[0].dtype == x.dtype and pend.owner[7] is be):
+                sink.arm_second(pend.owner[0], pend.owner[1], pend.owner[2])  # the downsample BN: same dz, same gate
         ctx.lazy_res = bool(lazy_res and relu and residual is not None and act is not None)
         ctx.save_for_backward(x, act if relu else None, mean, invstd, g32, count_t)
         ctx.cfg = (be, cfg, relu, world, count, residual is not None,
@@ -346,6 +367,7 @@ class _BNActFn(torch.autograd.Function):
         if ctx.defer is not None and not ctx.defer.consumed:
             raise RuntimeError("deferred BatchNorm apply: the un-normalised output was not consumed as the residual "
                                "of a fused BN node (pass defer_apply=False)")
+        psums2 = ctx.sink.take2(dz) if ctx.sink is not None else None  # (the downsample BN's, when the epilogue took both)
         psums = ctx.sink.take(dz) if ctx.sink is not None else None  # reduced by the consumer conv's dgrad epilogue
         gate = _take_gate(dz, getattr(ctx, "expect_gate", False))
         dz = _cl(dz)
@@ -378,7 +400,7 @@ class _BNActFn(torch.autograd.Function):
             # relu(bn(x) + bn_ds(x_ds)): the downsample BN receives this same dz with this same gate; one pass over
             # dz and the mask produces both input gradients, its backward then only hands the result on
             ox, omean, oinvstd, og32 = other
-            opsums = be.bn_bwd_reduce(dz, z, ox, omean, oinvstd, True)
+            opsums = psums2 if (psums2 is not None and gate is None) else be.bn_bwd_reduce(dz, z, ox, omean, oinvstd, True)
             dx, odx, sums, osums = be.bn_bwd_elemt2(dz, z, x, mean, invstd, g32, psums, ox, omean, oinvstd, og32,
                                                      opsums, count_t if world > 1 else count,
                                                      ipc=ctx.ipc.native if world > 1 else None)
@@ -412,6 +434,7 @@ class _BNActFn(torch.autograd.Function):
 
 DUAL_BN_BACKWARD = os.environ.get("PDT_DUAL_BN_BACKWARD", "1") != "0"  # bn3 + downsample BN in one pass over dz
 _FUSE_BN_REDUCE = os.environ.get("PDT_FUSE_BN_REDUCE", "1") != "0"
+_FUSE_DUAL_SUMS = os.environ.get("PDT_FUSE_DUAL_BN_SUMS", "1") != "0"  # ... and the downsample BN's sums in that epilogue too
 _FUSE_STEM_POOL_BWD = os.environ.get("PDT_FUSE_STEM_POOL_BWD", "1") != "0"  # stem tail backward without dz
 
 

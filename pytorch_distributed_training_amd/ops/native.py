@@ -107,9 +107,12 @@ def conv2d_fwd(x, w, stride: int, padding: int, want_stats: bool = False, return
 
 
 def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None, bn_sink=None, addend_mask=None,
-                 addend_stride: int = 1, cfg: int = 0):
+                 addend_stride: int = 1, cfg: int = 0, bn_sink2=None):
     """``bn_sink = (x, mask, mean, invstd)`` of the BN+ReLU that produced this conv's input: the kernel epilogue
     then also reduces that BN's backward sums and the call returns ``(dx, psums)`` (stride 1 only).
+    ``bn_sink2 = (x2, mean2, invstd2)``: a second BN fed by the same gradient through the same gate (the downsample
+    BN next to a bottleneck's bn3): the call returns ``(dx, psums, psums2)``, ``psums2`` None when the launch did not
+    go to the kernel that takes it (the caller then reduces on its own).
     ``addend_mask``: 1-bit activity mask ``[pixels, C/8]`` gating the addend (stride 1 only)."""
     kh, kw = w.shape[2], w.shape[3]
     wt = _transposed(w)  # [Cin][taps][Cout]: K-contiguous operand for the dgrad GEMM
@@ -117,9 +120,12 @@ def conv2d_dgrad(dy, w, x_shape, stride: int, padding: int, addend=None, bn_sink
         assert stride == 1 and addend_mask is None, "compact stride-2 addend: stride-1 data gradients only"
     if addend_mask is not None and stride != 1:
         addend, addend_mask = apply_relu_gate(addend, addend_mask), None
+    if bn_sink is not None and bn_sink2 is not None:
+        return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend, *bn_sink, addend_mask,
+                               addend_stride, cfg, *bn_sink2)
     if bn_sink is not None:
         return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend, *bn_sink, addend_mask,
-                               addend_stride, cfg)
+                               addend_stride, cfg)[:2]
     if addend is not None and stride != 1:
         return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, None, cfg=cfg)[0] + addend
     return _C.conv2d_dgrad(dy, wt, list(x_shape), kh, kw, stride, padding, addend, None, None, None, None,

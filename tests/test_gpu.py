@@ -580,6 +580,37 @@ def test_bn_backward_of_two_norms_sharing_a_gradient(shape):
         assert (got.float() - want).abs().max() <= 2e-2 * want.abs().max()
 
 
+@pytest.mark.parametrize("shape", [(4, 64, 256, 14, 14), (2, 128, 512, 9, 11), (3, 256, 1024, 7, 7), (17, 64, 256, 5, 5)])
+def test_dgrad_epilogue_takes_the_sums_of_both_norms_fed_by_its_result(shape):
+    """The pointwise data gradient on the GEMM core with a gated addend whose result is the gradient of a bottleneck's
+    bn3 AND of the downsample BN (k_gemm_nt<..., 2, false, DUAL>): the epilogue's second pair of sums against
+    bn_bwd_reduce of the same dx with the second BN's operands; dx and the first pair against the single-BN launch."""
+    from pytorch_distributed_training_amd.ops import native
+
+    torch.manual_seed(6)
+    B, N, C, H, W = shape  # dy [B, N, H, W] -> dx [B, C, H, W]
+    mk = lambda c: torch.randn(B, c, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy, add, x1, x2 = mk(N), mk(C), mk(C) * 2 + 1, mk(C) * 0.5 - 1
+    w = (torch.randn(N, C, 1, 1, device="cuda") / C ** 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    count = float(B * H * W)
+    m1, i1 = native.bn_finalize(native.bn_stats(x1), count, 1e-5)
+    m2, i2 = native.bn_finalize(native.bn_stats(x2), count, 1e-5)
+    g = torch.rand(C, device="cuda") + 0.5
+    z, mask = native.bn_apply_act(x1, m1, i1, g, torch.zeros(C, device="cuda"), x2, True)
+    gate = native.bn_apply_act(mk(C), m1, i1, g, torch.zeros(C, device="cuda"), None, True)[1]  # the addend's own gate
+    core = 100  # (kCfgGemmCore: these shapes are small on purpose)
+    dx1, ps1 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, 0, add, (x1, mask, m1, i1), gate, cfg=core)
+    dx2, ps1b, ps2 = native.conv2d_dgrad(dy, w, (B, C, H, W), 1, 0, add, (x1, mask, m1, i1), gate, cfg=core,
+                                         bn_sink2=(x2, m2, i2))
+    assert ps2 is not None and torch.equal(dx1, dx2)
+    assert torch.allclose(ps1.sum(0), ps1b.sum(0), rtol=1e-5, atol=1e-3)
+    want2 = native.bn_bwd_reduce(dx2, mask, x2, m2, i2, True).sum(0)
+    got2 = ps2.sum(0)
+    scale = want2.abs().max().clamp_min(1.0)
+    assert ((got2 - want2).abs().max() / scale) < 2e-3, ((got2 - want2).abs().max(), scale)
+    assert torch.allclose(got2[0], ps1.sum(0)[0], rtol=1e-5, atol=1e-3)  # sum g is shared
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 64, 112, 112), (5, 128, 8, 12), (70, 64, 32, 32)])
 def test_stem_tail_backward_gathers_the_pooled_gradient(shape):
     """bn_relu_maxpool_bwd (both BN-backward passes gather the max-pool gradient themselves; no full-resolution dz)
@@ -683,11 +714,22 @@ def test_toy_transformer_widths_stay_on_the_native_gemm():
     assert not new, new  # (one head of 32, width 32: attention, LayerNorm and every GEMM on the HIP kernels)
 
 
+_conv_port = [29720]
+
+
+def _convergence_port():
+    """(the session's own process group holds MASTER_PORT: every child job gets a port of its own)"""
+    _conv_port[0] += 1
+    return _conv_port[0]
+
+
 def _convergence_run(backend, extra_env, extra_args, td):
     args = ["--model", "resnet18", "--image_size", "64", "--num_classes", "100", "--batch_size", "64", "--steps", "80",
             "--window", "10", "--eval_batches", "8", "--noise", "0.4", "--seed", "0"]
     r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "bench", "convergence.py"), "--backend", backend] + args +
-                       extra_args, env={**os.environ, **extra_env, "PDT_QUIET": "1"}, cwd=td, stdout=subprocess.PIPE,
+                       extra_args, env={**os.environ, **extra_env, "PDT_QUIET": "1", "MASTER_ADDR": "127.0.0.1",
+                                        "MASTER_PORT": str(_convergence_port()), "RANK": "0", "WORLD_SIZE": "1",
+                                        "LOCAL_RANK": "0"}, cwd=td, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
