@@ -182,7 +182,8 @@ def test_main_py_two_ranks_gloo(tmp_path, free_port, repo_root):
     cmd = [sys.executable, "-m", "pytorch_distributed_training_amd.launch", "--nproc_per_node=2",
            f"--master_port={free_port}", os.path.join(repo_root, "main.py"), "--model", "resnet18", "--dataset",
            "synthetic-cifar10", "--dataset_len", "640", "--num_classes", "10", "--batch_size", "32", "--epochs", "1",
-           "--profile", "none", "--backend", "gloo", "--JobID", "T", "--checkpoint", "ck.pt", "--summary_json", "s.json"]
+           "--profile", "none", "--backend", "gloo", "--JobID", "T", "--checkpoint", "ck.pt", "--summary_json", "s.json",
+           "--grad_comm", "auto"]  # (CPU tensors: the IPC bucket path declines, the group carries the buckets)
     r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stdout.count("Start") == 2 and "Epoch: 0 step: 0 loss:" in r.stdout

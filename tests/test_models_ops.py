@@ -38,9 +38,12 @@ def test_resnet50_matches_torchvision_contract():
 
 
 @pytest.mark.parametrize("name,count", [("resnet18", 11_689_512), ("resnet34", 21_797_672), ("resnet101", 44_549_160),
-                                        ("resnet152", 60_192_808), ("vit_b_16", 86_567_656)])
+                                        ("resnet152", 60_192_808), ("vit_b_16", 86_567_656), ("vit_ti_16", 5_717_416),
+                                        ("vit_s_16", 22_050_664), ("vit_l_16", 304_326_632)])
 def test_parameter_counts(name, count):
-    assert sum(p.numel() for p in build_model(name).parameters()) == count
+    with torch.device("meta"):  # (shapes only: ViT-L/16 is 1.2 GB of fp32)
+        model = build_model(name)
+    assert sum(p.numel() for p in model.parameters()) == count
 
 
 def test_vit_state_dict_keys():
