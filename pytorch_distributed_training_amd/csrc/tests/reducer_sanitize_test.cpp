@@ -22,6 +22,13 @@
 #include "../binding/binding.h"
 #include "../reducer/reducer.h"
 
+// the IPC window launchers are device code (comm/ipc_allreduce.hip): this host-only build never reaches them (no
+// reducer here gets windows), the symbols only have to resolve
+namespace pdt {
+void launch_ipc_allreduce(float*, int, const IpcMailboxes&, hipStream_t) { std::abort(); }
+void launch_ipc_allreduce_large(void*, long, bool, const IpcMailboxes&, int, hipStream_t) { std::abort(); }
+}  // namespace pdt
+
 #define CHECK(cond)                                                                      \
     do {                                                                                 \
         if (!(cond)) {                                                                   \

@@ -44,7 +44,7 @@ def _sanitizer_build(tmp_path, name, san_flags):
            "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-D_GLIBCXX_USE_CXX11_ABI=1", *[f"-I{p}" for p in inc],
            f"-I{sysconfig.get_paths()['include']}",
            os.path.join(CSRC, "tests", "reducer_sanitize_test.cpp"), os.path.join(CSRC, "reducer", "reducer.cpp"),
-           os.path.join(CSRC, "comm", "rccl_comm.cpp"), "-o", exe, f"-L{lib}", "-ltorch", "-ltorch_cpu",
+           os.path.join(CSRC, "comm", "rccl_comm.cpp"), os.path.join(CSRC, "comm", "ipc_allreduce.cpp"), "-o", exe, f"-L{lib}", "-ltorch", "-ltorch_cpu",
            "-ltorch_hip", "-lc10", "-lc10_hip", "-lrccl", "-lamdhip64", "-lpthread", "-ldl", f"-Wl,-rpath,{lib}"]  # (torch's own ROCm libraries only: a second copy from /opt/rocm double-frees at exit)
     return exe, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 
