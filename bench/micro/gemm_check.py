@@ -80,7 +80,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--bn", type=int, default=0, help="force the tile width (128 / 256; 0: the launcher's choice)")
     a = ap.parse_args()
+    _C.set_gemm_tile_width(a.bn)
     ok = True
     # ragged M / N / K, every epilogue
     for (M, N, K) in [(256, 256, 64), (300, 264, 128), (17, 8, 72), (513, 1000, 2048), (1000, 512, 1000)]:

@@ -132,6 +132,15 @@ bool win64_enough(long B, long H) { return B * ((H + 3) / 4) >= 512; }
 // the round-1 kernels, 5.22 ms with the new ones on every layer, 4.1 again with this rule).
 bool enough_gemm_tiles(long M, long N) { return ((M + 255) / 256) * ((N + 255) / 256) >= 192; }
 
+// Output widths that are multiples of 128 but not of 256 on the GEMM core's 128-wide tile build (PDT_CONV_GEMM_N128=1)
+bool conv_gemm_n128() {
+    static const bool on = [] {
+        const char* e = std::getenv("PDT_CONV_GEMM_N128");
+        return e && std::string(e) == "1";
+    }();
+    return on;
+}
+
 bool conv_gemm_core_ok(long C, long N, long KH, long KW, long stride, long pad, int64_t cfg) {
     static const bool enabled = [] {
         const char* e = std::getenv("PDT_CONV_GEMM");
@@ -142,7 +151,7 @@ bool conv_gemm_core_ok(long C, long N, long KH, long KW, long stride, long pad, 
         TORCH_CHECK(eligible, "the GEMM core takes pointwise stride-1 convolutions with Cin % 64 == 0");
         return true;
     }
-    return cfg == 0 && enabled && eligible && N % 256 == 0;  // (+ enough_gemm_tiles at the call sites, which know M)
+    return cfg == 0 && enabled && eligible && (N % 256 == 0 || (conv_gemm_n128() && N % 128 == 0));  // (+ enough_gemm_tiles at the call sites, which know M)
 }
 
 // 3x3 / stride 1 / pad 1 on the GEMM core's spatial-filter mode (the taps go into the DMA's scalar offset, the zero
@@ -155,6 +164,7 @@ bool conv_gemm_taps_ok(long B, long C, long N, long H, long W, long KH, long KW,
     const bool eligible = KH == 3 && KW == 3 && stride == 1 && pad == 1 && C % 64 == 0 && N % 8 == 0 && W <= 126 &&
                           B * H * W < (1L << 31);
     if (cfg == kCfgGemmCore && eligible) return true;
+    if (cfg == 0 && enabled && eligible && conv_gemm_n128() && N % 128 == 0 && C >= 128 && enough_gemm_tiles(B * H * W, 256)) return true;
     return cfg == 0 && enabled && eligible && N % 256 == 0 && C >= 256 && enough_gemm_tiles(B * H * W, N);
 }
 // forward taps (dh, dw) = (r - pad, q - pad) with weight slot r * KW + q; data gradient: (pad - r, pad - q)
@@ -1552,6 +1562,7 @@ void bind_ops(pybind11::module& m) {
     m.def("gemm_nt", &gemm_nt, pybind11::arg("a"), pybind11::arg("b"), pybind11::arg("bias") = pybind11::none(),
           pybind11::arg("residual") = pybind11::none(), pybind11::arg("gelu_in") = pybind11::none(),
           pybind11::arg("act") = 0, pybind11::arg("want_preact") = false, pybind11::arg("want_colsum") = false);
+    m.def("set_gemm_tile_width", &set_gemm_tile_width, "force the GEMM core's tile width (128 / 256; 0: by shape)");
     m.def("linear_wgrad", &linear_wgrad);
     m.def("conv2d_fwd", &conv2d_fwd, pybind11::arg("x"), pybind11::arg("w"), pybind11::arg("stride"), pybind11::arg("pad"),
           pybind11::arg("want_stats"), pybind11::arg("cfg") = 0);

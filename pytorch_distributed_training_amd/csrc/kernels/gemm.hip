@@ -97,8 +97,19 @@ __device__ __forceinline__ int stage_off(int s) { return s ? STAGE1_OFF : 0; }
 // zero padding is per lane: 9 validity bits per staged row, computed once per tile.
 // DUAL (CONV == 2 only): a second BatchNorm takes the same gated gradient (kernels.h, bnr_x2): one more once-read operand
 // in the row pass and a third per-column sum; its own build so that the common one keeps its registers.
-template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV, bool TAPS, bool DUAL = false>
+// BNT: tile width, 256 or 128.  The 128-wide build has no B-hi half-tile (DMA slot 3 stays empty), its waves own 128 x 32
+// of the tile (8 x 2 accumulators, 8 MFMAs per phase) and the store pass covers 32 rows per pass.  It moves 48 KiB
+// through the L2 -> LDS path per K-tile of 256 x 128 x 64 (1.5x the bytes per FLOP of the square tile), so it is for
+// outputs that ARE 128 wide (the 128-channel 3x3 and pointwise layers) and for tile counts that leave the last round
+// of square tiles mostly empty (ViT at small batch: 297 tiles on 256 CUs).
+template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV, bool TAPS, bool DUAL = false, int BNT = 256>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
+    static_assert(BNT == 256 || BNT == 128, "tile width");
+    constexpr int NJ = BNT / 64;            // 16-column accumulator groups per wave
+    constexpr int CPR = BNT / 8;            // 16-B chunks per staged output row
+    constexpr int RPP = 512 / CPR;          // rows per store pass
+    constexpr int NPASS = 128 / RPP;        // store passes per half tile
+    constexpr int OPITCH_T = BNT * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,9 +153,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
         const int tn = rem / band_rows;
         tile_m = band * a.group_m + (rem - tn * band_rows);
         m0 = (long)tile_m * BM;
-        n0 = tn * BN;
+        n0 = tn * BNT;
         rows_m = (int)((a.M - m0) < BM ? (a.M - m0) : BM);
-        rows_n = (a.N - n0) < BN ? (a.N - n0) : BN;
+        rows_n = (a.N - n0) < BNT ? (a.N - n0) : BNT;
         // descriptors re-based at the tile's first row: offsets inside stay far below 2^31
         // (TAPS: the window is widened by the halo on both sides in case the range check sees the scalar offset;
         // every lane whose shifted row leaves the image, and with it the tensor, is masked explicitly)
@@ -176,8 +187,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
     const int nt = TAPS ? a.ntaps * (a.K / BK) : (a.K + BK - 1) / BK;
     // slot: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi; t = K-tile of the current operand state; par = its stage buffer
     auto issue = [&](int hslot, int t, int par) {
+        if (BNT == 128 && hslot == 3) return;  // (no B-hi half: the counted waits below only assume "2 per issue")
         if (a.debug_nostore & 8) return;  // (timing diagnostics: no operand DMA)
-        const uint32_t dst = piece_base + (uint32_t)(stage_off(par) + hslot * HALF_BYTES);
+        uint32_t dst = piece_base + (uint32_t)(stage_off(par) + hslot * HALF_BYTES);
+        if (BNT == 128) dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst);  // (this build loses track of its uniformity)
         const bool isB = hslot >= 2;
         const int h = hslot & 1;
         const int ld2 = (isB ? a.ldb : a.lda) * 2;
@@ -211,10 +224,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
     for (int ks = 0; ks < 2; ++ks) {
         const int lo = l15 * 128 + (((ks * 4 + lq) ^ (l15 >> 1)) << 4);
         a_off[ks] = wr * HALF_BYTES + lo;
-        b_off[ks] = 2 * HALF_BYTES + (wc >> 1) * HALF_BYTES + (wc & 1) * 64 * 128 + lo;
+        b_off[ks] = BNT == 256 ? 2 * HALF_BYTES + (wc >> 1) * HALF_BYTES + (wc & 1) * 64 * 128 + lo
+                               : 2 * HALF_BYTES + wc * 32 * 128 + lo;
     }
-    const int och = tid & 31, orow = tid >> 5;  // store pass: 32 chunks of 8 columns per row, 16 rows per pass
-    constexpr int PB = CONV == 2 ? (DUAL ? 2 : 4) : 8;  // passes whose global reads are in flight together
+    const int och = tid & (CPR - 1), orow = tid / CPR;  // store pass: CPR chunks of 8 columns per row, RPP rows per pass
+    constexpr int PB0 = CONV == 2 ? (DUAL ? 2 : 4) : 8;  // passes whose global reads are in flight together
+    constexpr int PB = PB0 < NPASS ? PB0 : NPASS;
 
     // ---- prologue of the first tile: K-tile 0
     int gk = 0;  // K-tiles consumed so far: K-tile t of the current tile lives in stage (gk + t) & 1
@@ -227,14 +242,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
     __builtin_amdgcn_s_barrier();
 
     while (true) {
-        f32x4_t acc[8][4];
+        f32x4_t acc[8][NJ];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
         if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one phase behind their SIMD partners
-        bf16x8 bfrag[2][4];
+        bf16x8 bfrag[2][NJ];
         for (int t = 0; t < nt; ++t) {
             const int par = (gk + t) & 1;
             const char* st = smem + stage_off(par);
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                     afrag[i] = *reinterpret_cast<const bf16x8*>(st + a_off[ks] + (mh * 64 + i * 16) * 128);
                 if (mh == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         bfrag[ks][j] = *reinterpret_cast<const bf16x8*>(st + b_off[ks] + j * 16 * 128);
                 }
                 if (ph == 0) {
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < NJ; ++j)
                             acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[ks][j], afrag[i],
                                                                                           acc[mh * 4 + i][j], 0, 0, 0);
                 } else {
@@ -347,9 +362,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
             if (a.debug_nostore & 2) break;  // (timing diagnostics: no staging, no row pass)
             if (wr == hh) {
                 // lane holds, for 16x16 tile (i, j): row i*16 + lane%16, columns j*16 + (lane/16)*4 + 0..3
-                const int wcol = wc * 64 + lq * 4;
+                const int wcol = wc * (BNT / 4) + lq * 4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
                     const int n = on0 + wcol + j * 16;
                     if (CONV == 0 && a.bias != nullptr && n < a.N) bv = *reinterpret_cast<const f32x4_t*>(a.bias + n);  // N % 4 == 0
@@ -357,7 +372,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                     for (int i = 0; i < 8; ++i) {
                         const f32x4_t v = acc[i][j] + bv;
                         const bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        *reinterpret_cast<bf16x4*>(Os + (i * 16 + l15) * OPITCH + (((wc * 8 + j * 2 + (lq >> 1)) ^ (l15 & 7)) << 4) +
+                        *reinterpret_cast<bf16x4*>(Os + (i * 16 + l15) * OPITCH_T +
+                                                   (((wc * (BNT / 32) + j * 2 + (lq >> 1)) ^ (l15 & 7)) << 4) +
                                                    (((lq & 1) ^ (l15 >> 3)) << 3)) = pk;
                     }
                 }
@@ -368,19 +384,19 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
             // read from global memory is fetched for a whole batch first; every thread issues one store per pass
             // (masked ones are dropped by the descriptor's range check).
 #pragma unroll
-            for (int pb = 0; pb < 8; pb += PB) {
+            for (int pb = 0; pb < NPASS; pb += PB) {
                 bf16x8 ev[PB], bx[CONV == 2 ? PB : 1], bx2[DUAL ? PB : 1];
                 unsigned abits[CONV == 2 ? PB : 1], bbits[CONV == 2 ? PB : 1];
                 uint32_t coff[PB];
 #pragma unroll
                 for (int p = 0; p < PB; ++p) {
-                    const int row = hh * 128 + (pb + p) * 16 + orow;
+                    const int row = hh * 128 + (pb + p) * RPP + orow;
                     coff[p] = col_ok ? (uint32_t)row * (uint32_t)(a.ldc * 2) + (uint32_t)(ncol * 2) : kOOB;
                 }
                 if (EXTRA != 0 || CONV == 2) {
 #pragma unroll
                     for (int p = 0; p < PB; ++p) {
-                        const int row = hh * 128 + (pb + p) * 16 + orow;
+                        const int row = hh * 128 + (pb + p) * RPP + orow;
                         const uint32_t eo = col_ok ? (uint32_t)row * (uint32_t)(lde * 2) + (uint32_t)(ncol * 2) : kOOB;
                         if (EXTRA != 0 || has_add) ev[p] = buffer_load_bf16x8_stream(re, eo);
                         if (CONV == 2) {
@@ -398,9 +414,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                 }
 #pragma unroll
                 for (int p = 0; p < PB; ++p) {
-                    const int lrow = (pb + p) * 16 + orow;
-                    bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + lrow * OPITCH + ((och ^ (orow & 7)) << 4));
-                    if (wave >= 4) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);  // rows with bit 3 set
+                    const int lrow = (pb + p) * RPP + orow;
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + lrow * OPITCH_T + ((och ^ (orow & 7)) << 4));
+                    if ((orow >> 3) & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);  // rows with bit 3 set (wave-uniform)
                     if (ACT)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, coff[p], 0, kAuxStream);
                     if (ACT) {
@@ -453,8 +469,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
         }
         // The next tile's first K-tile was issued before this thread's 16 (32 with the pre-activation) stores and
         // vmcnt retires in issue order: at most that many operations outstanding means the DMA has landed.
-        if (ACT) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (BNT == 256) {
+            if (ACT) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {  // (2 halves x 4 passes: 8 stores per thread, 16 with the pre-activation)
+            if (ACT) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
         const bool want_sums = COLSUM || CONV == 1 || (CONV == 2 && bnr);
         if (want_sums) {
             // per-tile column sums of what was stored: threads och + 32 * r own the same 8 columns: lanes l and
@@ -467,24 +488,29 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                 csum[k] += __shfl_xor(csum[k], 32, 64);
                 if (SUMS2) csq[k] += __shfl_xor(csq[k], 32, 64);
                 if (DUAL) csq2[k] += __shfl_xor(csq2[k], 32, 64);
+                if (BNT == 128) {  // 16 chunks per row: lanes l, l^16, l^32, l^48 own the same columns
+                    csum[k] += __shfl_xor(csum[k], 16, 64);
+                    if (SUMS2) csq[k] += __shfl_xor(csq[k], 16, 64);
+                    if (DUAL) csq2[k] += __shfl_xor(csq2[k], 16, 64);
+                }
             }
-            if (lane < 32) {
+            if (lane < CPR) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    Ss[wave * BN + och * 8 + k] = csum[k];
-                    if (SUMS2) Ss[(8 + wave) * BN + och * 8 + k] = csq[k];
-                    if (DUAL) Ss[(16 + wave) * BN + och * 8 + k] = csq2[k];
+                    Ss[wave * BNT + och * 8 + k] = csum[k];
+                    if (SUMS2) Ss[(8 + wave) * BNT + och * 8 + k] = csq[k];
+                    if (DUAL) Ss[(16 + wave) * BNT + och * 8 + k] = csq2[k];
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (tid < BN && on0 + tid < a.N) {
+            if (tid < BNT && on0 + tid < a.N) {
                 float s = 0.f, q = 0.f, q2 = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
-                    s += Ss[w * BN + tid];
-                    if (SUMS2) q += Ss[(8 + w) * BN + tid];
-                    if (DUAL) q2 += Ss[(16 + w) * BN + tid];
+                    s += Ss[w * BNT + tid];
+                    if (SUMS2) q += Ss[(8 + w) * BNT + tid];
+                    if (DUAL) q2 += Ss[(16 + w) * BNT + tid];
                 }
                 if (DUAL) {  // same row layout as stats_slab: [sum g (shared), sum g * xhat2]
                     float* dst2 = a.stats_slab2 + (long)otile_m * 2 * a.N;
@@ -510,21 +536,40 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
 
 int gemm_m_tiles(long M) { return (int)((M + BM - 1) / BM); }
 
-template <int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV, bool TAPS = false, bool DUAL = false>
+template <int BNT, int EXTRA, bool ACT, bool COLSUM, bool RAGGED, int CONV, bool TAPS = false, bool DUAL = false>
 static void launch_variant(const GemmArgs& a, int grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV, TAPS, DUAL>),
+        PDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV, TAPS, DUAL, BNT>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV, TAPS, DUAL>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_gemm_nt<EXTRA, ACT, COLSUM, RAGGED, CONV, TAPS, DUAL, BNT>), dim3(grid), dim3(512), LDS_BYTES, s, a);
 }
 
-void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
-    GemmArgs a = args;
-    a.m_tiles = gemm_m_tiles(a.M);
-    a.n_tiles = (a.N + BN - 1) / BN;
+// Tile width for a launch (GemmArgs::bn = 0): 128 only when the output is no wider than that.  Measured (round 3,
+// profiles/r3_gemm_bn128.md): a 128-wide tile takes 0.62-0.65 of a square tile's time, not 0.5 (1.5x the operand
+// bytes per FLOP through L2 -> LDS), so it loses even where it removes a mostly empty last round of square tiles
+// (ViT-B/16 at B = 128, N = 768: 297 square tiles on 256 CUs, 59.0 us square vs 66.6 us narrow; the step 23.3 vs 24.5 ms)
+// and on ResNet-50's 128-channel layers against the implicit-GEMM builds (15 285 vs 15 082 img/s at B = 1280).
+// PDT_GEMM_BN=256|128 or set_gemm_tile_width() forces one.
+static int g_forced_bn = [] {
+    const char* e = std::getenv("PDT_GEMM_BN");
+    return e ? std::atoi(e) : 0;
+}();
+void set_gemm_tile_width(int bn) { g_forced_bn = bn; }
+
+static int pick_tile_width(const GemmArgs& a, int cus) {
+    const int forced = g_forced_bn;
+    if (a.bn == 128 || a.bn == 256) return a.bn;
+    if (forced == 128 || forced == 256) return forced;
+    (void)cus;
+    return a.N <= 128 ? 128 : 256;
+}
+
+template <int BNT>
+static void launch_width(GemmArgs& a, int cus, hipStream_t s) {
+    a.n_tiles = (a.N + BNT - 1) / BNT;
     // (K-tiles are 64 elements = whole 128-B lines.  The same hint on the implicit-GEMM kernel's 64-B K-steps LOST 2.7 %
     // of the step: the second half of every line came from memory again.)  PDT_GEMM_A_STREAM=0: off.
     static const bool a_stream_on = [] {
@@ -532,21 +577,10 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
         return !(e && e[0] == '0');
     }();
     a.a_stream = a_stream_on && a.n_tiles == 1 && a.ntaps == 0 ? 1 : 0;
-    if (a.M <= 0 || a.N <= 0) return;
     // 32 tiles run together on one XCD: with many tile columns walk bands of 4 tile rows (4 A panels + 8 B panels
     // per K-step instead of 1 + 32)
     a.group_m = a.n_tiles > 12 ? 4 : 1;
-    // timing diagnostics only (results are wrong): PDT_GEMM_NOSTORE, or PDT_GEMM_DEBUG = bit mask of 1 drop the
-    // output stores, 2 skip the epilogue, 4 skip the MFMAs, 8 skip the operand DMA; re-read at every launch
-    const char* dbg = std::getenv("PDT_GEMM_DEBUG");
-    a.debug_nostore = (std::getenv("PDT_GEMM_NOSTORE") != nullptr ? 1 : 0) | (dbg ? std::atoi(dbg) : 0);
     const int total = a.m_tiles * a.n_tiles;
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-        const char* e = std::getenv("PDT_GEMM_GRID");
-        return e ? std::atoi(e) : n;
-    }();
     const int grid = total < cus ? total : cus;
     const bool ragged = a.K % BK != 0, colsum = a.colsum_slab != nullptr;
     const int extra = a.residual ? 1 : (a.gelu_in ? 2 : 0);
@@ -565,9 +599,9 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
         a.div_w = make_fastdiv((uint32_t)a.W);
         a.div_hw = make_fastdiv((uint32_t)(a.H * a.W));
         a.div_kt = make_fastdiv((uint32_t)(a.K / BK));
-        if (a.conv_mode == 1) launch_variant<0, false, false, false, 1, true>(a, grid, s);
-        else if (a.conv_mode == 2) launch_variant<0, false, false, false, 2, true>(a, grid, s);
-        else launch_variant<0, false, false, false, 0, true>(a, grid, s);
+        if (a.conv_mode == 1) launch_variant<BNT, 0, false, false, false, 1, true>(a, grid, s);
+        else if (a.conv_mode == 2) launch_variant<BNT, 0, false, false, false, 2, true>(a, grid, s);
+        else launch_variant<BNT, 0, false, false, false, 0, true>(a, grid, s);
         return;
     }
     if (a.conv_mode != 0) {
@@ -584,9 +618,9 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
             fprintf(stderr, "launch_gemm_nt: second BatchNorm operand without the first / its statistics\n");
             abort();
         }
-        if (a.conv_mode == 1) launch_variant<0, false, false, false, 1>(a, grid, s);
-        else if (a.bnr_x2) launch_variant<0, false, false, false, 2, false, true>(a, grid, s);
-        else launch_variant<0, false, false, false, 2>(a, grid, s);
+        if (a.conv_mode == 1) launch_variant<BNT, 0, false, false, false, 1>(a, grid, s);
+        else if (a.bnr_x2) launch_variant<BNT, 0, false, false, false, 2, false, true>(a, grid, s);
+        else launch_variant<BNT, 0, false, false, false, 2>(a, grid, s);
         return;
     }
     if ((a.residual && a.gelu_in) || (act && (extra || colsum || !a.preact_out)) || (!act && a.preact_out) ||
@@ -594,11 +628,38 @@ void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
         fprintf(stderr, "launch_gemm_nt: unsupported epilogue combination\n");
         abort();
     }
-    if (act) launch_variant<0, true, false, false, 0>(a, grid, s);
-    else if (extra == 1) colsum ? launch_variant<1, false, true, false, 0>(a, grid, s) : launch_variant<1, false, false, false, 0>(a, grid, s);
-    else if (extra == 2) colsum ? launch_variant<2, false, true, false, 0>(a, grid, s) : launch_variant<2, false, false, false, 0>(a, grid, s);
-    else if (ragged) colsum ? launch_variant<0, false, true, true, 0>(a, grid, s) : launch_variant<0, false, false, true, 0>(a, grid, s);
-    else colsum ? launch_variant<0, false, true, false, 0>(a, grid, s) : launch_variant<0, false, false, false, 0>(a, grid, s);
+    if (act) launch_variant<BNT, 0, true, false, false, 0>(a, grid, s);
+    else if (extra == 1) colsum ? launch_variant<BNT, 1, false, true, false, 0>(a, grid, s) : launch_variant<BNT, 1, false, false, false, 0>(a, grid, s);
+    else if (extra == 2) colsum ? launch_variant<BNT, 2, false, true, false, 0>(a, grid, s) : launch_variant<BNT, 2, false, false, false, 0>(a, grid, s);
+    else if (ragged) colsum ? launch_variant<BNT, 0, false, true, true, 0>(a, grid, s) : launch_variant<BNT, 0, false, false, true, 0>(a, grid, s);
+    else colsum ? launch_variant<BNT, 0, false, true, false, 0>(a, grid, s) : launch_variant<BNT, 0, false, false, false, 0>(a, grid, s);
+}
+
+int gemm_tile_width(const GemmArgs& a) {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n;
+    }();
+    return pick_tile_width(a, cus);
+}
+
+void launch_gemm_nt(const GemmArgs& args, hipStream_t s) {
+    GemmArgs a = args;
+    if (a.M <= 0 || a.N <= 0) return;
+    a.m_tiles = gemm_m_tiles(a.M);
+    // timing diagnostics only (results are wrong): PDT_GEMM_NOSTORE, or PDT_GEMM_DEBUG = bit mask of 1 drop the
+    // output stores, 2 skip the epilogue, 4 skip the MFMAs, 8 skip the operand DMA; re-read at every launch
+    const char* dbg = std::getenv("PDT_GEMM_DEBUG");
+    a.debug_nostore = (std::getenv("PDT_GEMM_NOSTORE") != nullptr ? 1 : 0) | (dbg ? std::atoi(dbg) : 0);
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        const char* e = std::getenv("PDT_GEMM_GRID");
+        return e ? std::atoi(e) : n;
+    }();
+    if (pick_tile_width(a, cus) == 128) launch_width<128>(a, cus, s);
+    else launch_width<256>(a, cus, s);
 }
 
 }  // namespace pdt

@@ -281,6 +281,7 @@ struct GemmArgs {
     int a_stream;  // (set by launch_gemm_nt) one tile column: A is read exactly once -> non-temporal DMA
     int32_t tap[9];  // (dh & 0xff) | (dw & 0xff) << 8 | wslot << 16
     FastDiv div_w, div_hw, div_kt;  // / W, / (H * W), / (K / 64)
+    int bn;                         // tile width: 0 = the launcher picks (gemm_tile_width), 128 or 256
     int m_tiles, n_tiles, group_m;  // filled by the launcher
     int debug_nostore;              // timing diagnostics, bit mask: 1 output stores dropped (zero-size descriptor),
                                     // 2 epilogue skipped, 4 MFMAs skipped, 8 operand DMA skipped
@@ -298,6 +299,8 @@ void set_gemm_tn_min_rows(long rows);  // reduction length from which it is used
 int gemm_tn_splits(const WgradGeom& g);
 void launch_gemm_tn(const void* dy, const void* x, float* slab, const WgradGeom& g, hipStream_t s);
 int gemm_m_tiles(long M);
+void set_gemm_tile_width(int bn);  // process-wide override of the choice (0: by shape; tests and A/B runs)
+int gemm_tile_width(const GemmArgs& a);  // what launch_gemm_nt will use for this launch (a.bn == 0: by shape)
 void launch_gemm_nt(const GemmArgs& a, hipStream_t s);
 
 // ---- ViT glue (vit.hip) -----------------------------------------------------------------------------------

@@ -239,6 +239,54 @@ def test_gemm_fused_epilogues(gc, mnk, kw):
     assert gc.check(*mnk, timing=False, **kw)
 
 
+@pytest.fixture()
+def narrow_tiles():
+    """every GEMM-core launch inside the test on the 256 x 128 tile build (gemm.hip, BNT = 128)"""
+    ext = pdt.require_native()
+    ext.set_gemm_tile_width(128)
+    yield ext
+    ext.set_gemm_tile_width(0)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(bias=True), dict(bias=True, act=1, preact=True), dict(bias=True, residual=True),
+                                dict(gelu_in=True, colsum=True), dict(colsum=True), dict(residual=True, colsum=True)])
+@pytest.mark.parametrize("mnk", [(777, 520, 192), (66000, 768, 128), (300, 128, 1000), (513, 1000, 2048)])
+def test_gemm_128_wide_tile_build(gc, narrow_tiles, mnk, kw):
+    """The 128-wide tile build of the GEMM core (no B-hi half-tile, 8 x 2 accumulators per wave, 32-row store passes)
+    on every epilogue: ragged M / N / K (K % 64 != 0 only without a fused operand, as in the square build), more tiles
+    than workgroups (66000 rows x 6 tile columns = 1548 tiles)."""
+    if mnk[2] % 64 != 0 and (kw.get("act") or kw.get("residual") or kw.get("gelu_in")):
+        pytest.skip("ragged K takes no fused operand (launch_gemm_nt)")
+    assert gc.check(*mnk, timing=False, **kw)
+
+
+@pytest.mark.parametrize("case", [
+    (5, 64, 23, 23, 128, 1, 1, 0), (5, 256, 19, 19, 128, 1, 1, 0), (3, 128, 21, 21, 384, 1, 1, 0), (16, 512, 28, 28, 128, 1, 1, 0),
+    (3, 128, 9, 7, 128, 3, 1, 1), (5, 128, 28, 28, 128, 3, 1, 1), (2, 256, 14, 14, 256, 3, 1, 1), (1, 64, 5, 3, 640, 3, 1, 1)])
+def test_conv_on_gemm_core_128_wide_tiles(kc, narrow_tiles, case):
+    """Pointwise and 3x3 convolutions forced onto the GEMM core with its 128-wide tiles: forward + BN statistics, data
+    gradient plain / + gated addend / + fused BN-backward sums, against fp32 and the implicit-GEMM kernel."""
+    n = len(kc.RESULTS)
+    kc.check_conv(case, False, cfg=kc.GEMM_CORE)
+    _assert_all_ok(kc, n)
+
+
+def test_gemm_tile_width_choice_gives_identical_products():
+    """256- and 128-wide tiles sum every output element over the same K order: bit-identical results"""
+    ext = pdt.require_native()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randn(3000, 320, device="cuda", generator=g).to(torch.bfloat16)
+    b = torch.randn(768, 320, device="cuda", generator=g).to(torch.bfloat16)
+    try:
+        ext.set_gemm_tile_width(256)
+        c256 = ext.gemm_nt(a, b)[0]
+        ext.set_gemm_tile_width(128)
+        c128 = ext.gemm_nt(a, b)[0]
+    finally:
+        ext.set_gemm_tile_width(0)
+    assert torch.equal(c256, c128)
+
+
 def test_gemm_identity_weight_asymmetric_input():
     """A = asymmetric integers, B = I: the output must be A (catches a transposed accumulator map or swapped operands)"""
     ext = pdt.require_native()
