@@ -1562,6 +1562,7 @@ void bind_ops(pybind11::module& m) {
     m.def("gemm_nt", &gemm_nt, pybind11::arg("a"), pybind11::arg("b"), pybind11::arg("bias") = pybind11::none(),
           pybind11::arg("residual") = pybind11::none(), pybind11::arg("gelu_in") = pybind11::none(),
           pybind11::arg("act") = 0, pybind11::arg("want_preact") = false, pybind11::arg("want_colsum") = false);
+    m.def("set_attention_pipelined", &set_attention_pipelined, "whole-head attention of 5+ tiles on the persistent pipelined kernels (default on)");
     m.def("set_gemm_tile_width", &set_gemm_tile_width, "force the GEMM core's tile width (128 / 256; 0: by shape)");
     m.def("linear_wgrad", &linear_wgrad);
     m.def("conv2d_fwd", &conv2d_fwd, pybind11::arg("x"), pybind11::arg("w"), pybind11::arg("stride"), pybind11::arg("pad"),

@@ -33,6 +33,7 @@ namespace {
 
 constexpr int HD = 64;        // head dim
 constexpr int ROWB = HD * 2;  // LDS row bytes
+constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kNegBig = -1e30f;  // finite stand-in for -inf (the kernels are built with -ffast-math)
 
 typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
@@ -325,6 +326,366 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd(const bf16* __restrict__ q
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qq = qt * 32 + acc_row(r, half);
+            if (qq < S) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) dq_base[(long)qq * rs + dt * 32 + l31] = (bf16)(dq[dt][r] * 0.125f);
+            }
+        }
+    }
+}
+
+// ===================================================================== whole head, persistent and software-pipelined
+// The kernels above run one head per workgroup and fetch it with global loads that are written to LDS one at a time
+// (load -> wait -> ds_write per 16 B, 11 dependent round trips before the first MFMA) with one workgroup per CU
+// (201 / 180 registers): at ViT-B/16's 197 tokens they reach ~200 TFLOP/s, a third of what their own HBM traffic
+// allows.  The kernels below keep the arithmetic and change the data movement:
+//  * one workgroup per CU walks over heads (grid = CUs, head = blockIdx + k * grid);
+//  * operands arrive by LDS-DMA (buffer_load ... lds, 1 KiB = 8 rows per wave instruction) with the swizzle applied to
+//    the SOURCE chunk and rows past S sent out of range (zeros): no register round trip, everything in flight at once;
+//  * the next head's operands are fetched while the current head is computed.  Forward: two (K, V) buffers.  Backward:
+//    the key-owner pass reads Q / dO / O images and the wave's own K / V rows (prefetched into registers), the
+//    query-owner pass reads K / V images and the wave's own Q / dO rows (taken from LDS at the end of the first pass),
+//    so K / V of this head land during the first pass and Q / dO / O of the NEXT head during the second: five images
+//    (140 KiB at 7 tiles) instead of eight;
+//  * D[q] = sum_d dO * O comes from the two LDS images (the O image exists for this alone: 28 KiB of LDS against a
+//    second read of O and dO by a pre-pass), the softmax scale moves from the staged Q to the fp32 scores;
+//  * waits are counted: the stores of a head (issued after the next head's DMA) are not waited for.
+template <int NT, int NW>
+__device__ __forceinline__ void stage_dma(uint32_t img_lds, const bf16* src, long row_stride, int S, int wave, int lane) {
+    i32x4 rsrc = make_rsrc_words(src, (uint32_t)((long)(S - 1) * row_stride * 2 + ROWB));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rsrc[k] = __builtin_amdgcn_readfirstlane(rsrc[k]);  // (head index: uniform, but the compiler cannot see it)
+#pragma unroll
+    for (int i = 0; i < (NT * 4 + NW - 1) / NW; ++i) {
+        const int p = wave + i * NW;  // piece of 8 rows; wave-uniform
+        if (p < NT * 4) {
+            const int row = p * 8 + (lane >> 3);
+            const int x = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+            const uint32_t off = row < S ? (uint32_t)row * (uint32_t)(row_stride * 2) + (uint32_t)(((lane & 7) ^ x) << 4) : kOOB;
+            lds_dma16(rsrc, off, (uint32_t)__builtin_amdgcn_readfirstlane((int)(img_lds + (uint32_t)p * 1024u)));
+        }
+    }
+}
+// a wave's own 32 rows of a [*, row_stride] tensor as MFMA fragments from global memory; rows past S read row S - 1
+// (their results are masked or never stored)
+__device__ __forceinline__ void own_rows64(bf16x8* f, const bf16* src, long row_stride, int row, int S, int half) {
+    const int rc = row < S ? row : S - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const bf16x8*>(src + (long)rc * row_stride + s * 16 + half * 8);
+}
+__device__ __forceinline__ void pin(bf16x8* f) {  // the fragments exist in registers HERE (nothing of them is loaded later)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(f[s])::"memory");
+}
+
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attn_fwd_p(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                        float* __restrict__ lse, int S, int H, int BH) {
+    constexpr int SP = NT * 32, IMG = SP * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K image, V image]
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long D = (long)H * HD, rs = 3 * D;
+    const uint32_t lds0 = lds_address(smem);
+    const int q = wave * 32 + l31;  // this wave's query tile is tile `wave` of every head
+    auto head_base = [&](int bh) { return qkv + (long)(bh / H) * S * rs + (bh % H) * HD; };
+    auto issue_kv = [&](int bh, int buf) {
+        const bf16* base = head_base(bh);
+        stage_dma<NT, NW>(lds0 + (uint32_t)(buf * 2 * IMG), base + D, rs, S, wave, lane);
+        stage_dma<NT, NW>(lds0 + (uint32_t)(buf * 2 * IMG + IMG), base + 2 * D, rs, S, wave, lane);
+    };
+    int bh = blockIdx.x, buf = 0;
+    if (bh >= BH) return;
+    bf16x8 bqn[4];
+    issue_kv(bh, 0);
+    if (wave < NT) own_rows64(bqn, head_base(bh), rs, q, S, half);
+    bool stored = false;  // (first head: nothing was issued after its DMA)
+    for (; bh < BH; bh += gridDim.x, buf ^= 1) {
+        bf16x8 bq[4];
+        if (wave < NT) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bq[s][k] = (bf16)((float)bqn[s][k] * 0.125f);
+            pin(bq);
+        }
+        // the previous head's 33 stores were issued after this head's DMA and query rows: a wave with a full tile
+        // may leave them in flight
+        if (stored && wave < NT - 1) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stored = true;
+        __builtin_amdgcn_s_barrier();  // this head's images are complete; nobody reads the other buffer any more
+        const int nbh = bh + (int)gridDim.x;
+        if (nbh < BH) issue_kv(nbh, buf ^ 1);
+        if (wave >= NT) continue;
+        const char* Ks = smem + buf * 2 * IMG;
+        const char* Vs = Ks + IMG;
+        const int b = bh / H, h = bh % H;
+        // S^T tiles: rows = keys, lane = query
+        f32x16 st[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32 + l31, s, half), bq[s], st[kt], 0, 0, 0);
+        }
+        // the next head's query rows, into the registers the scores no longer need (in flight during softmax and P V)
+        __builtin_amdgcn_sched_barrier(0);
+        if (nbh < BH) own_rows64(bqn, head_base(nbh), rs, q, S, half);
+        __builtin_amdgcn_sched_barrier(0);
+        float m = kNegBig;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (kt == NT - 1 && kt * 32 + acc_row(r, half) >= S) st[kt][r] = kNegBig;  // (S > 32 * (NT - 1): only the last tile has padding)
+                m = fmaxf(m, st[kt][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float mneg = -m * kLog2e;
+        float sum = 0.f;
+        bf16x8 pa[NT][2];  // P as the bf16 A operands of the second product (half the registers of the fp32 scores)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], kLog2e, mneg));  // one FMA + v_exp_f32
+                st[kt][r] = p;
+                sum += p;
+            }
+            pa[kt][0] = acc_to_a(st[kt], 0);
+            pa[kt][1] = acc_to_a(st[kt], 1);
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[kt][blk], frag_cols(Vs, kt * 32 + blk * 16, dt * 32, lane),
+                                                                   o[dt], 0, 0, 0);
+            }
+        const float inv = 1.f / sum;
+        // exactly 33 store instructions per wave with a full tile (the counted wait above relies on it): masked lanes
+        // are switched off, the instructions are issued all the same
+        if (q < S && half == 0) lse[((long)b * H + h) * S + q] = m + __logf(sum);
+        bf16* orow = out + ((long)b * S * H + h) * HD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = acc_row(r, half);
+            const float invr = __shfl(inv, qr, 64);
+            const int qq = wave * 32 + qr;
+            if (qq < S) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) orow[(long)qq * D + dt * 32 + l31] = (bf16)(o[dt][r] * invr);
+            }
+        }
+    }
+}
+
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attn_bwd_p(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                        const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                        bf16* __restrict__ dqkv, int S, int H, int BH) {
+    constexpr int SP = NT * 32, IMG = SP * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;                       // raw (the 1/8 goes onto the fp32 scores)
+    char* Os = Qs + IMG;                   // dO
+    char* Zs = Os + IMG;                   // O (for D only)
+    char* Ks = Zs + IMG;
+    char* Vs = Ks + IMG;
+    float* Ls = reinterpret_cast<float*>(Vs + IMG);  // lse[q] * log2(e)   (huge on padding rows: P = 0 there)
+    float* Ds = Ls + SP;                             // D[q] = sum_d dO * O
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long D = (long)H * HD, rs = 3 * D;
+    const uint32_t lds0 = lds_address(smem);
+    const int own = wave * 32 + l31;  // this wave's key (first pass) / query (second pass) row
+    auto head_base = [&](int bh) { return qkv + (long)(bh / H) * S * rs + (bh % H) * HD; };
+    auto issue_x = [&](int bh) {
+        const long o = ((long)(bh / H) * S * H + (bh % H)) * HD;
+        stage_dma<NT, NW>(lds0, head_base(bh), rs, S, wave, lane);
+        stage_dma<NT, NW>(lds0 + (uint32_t)IMG, dout + o, D, S, wave, lane);
+        stage_dma<NT, NW>(lds0 + (uint32_t)(2 * IMG), out + o, D, S, wave, lane);
+    };
+    auto issue_y = [&](int bh) {
+        stage_dma<NT, NW>(lds0 + (uint32_t)(3 * IMG), head_base(bh) + D, rs, S, wave, lane);
+        stage_dma<NT, NW>(lds0 + (uint32_t)(4 * IMG), head_base(bh) + 2 * D, rs, S, wave, lane);
+    };
+    int bh = blockIdx.x;
+    if (bh >= BH) return;
+    bf16x8 kfn[4], vfn[4];
+    float ln = 0.f;
+    auto prefetch = [&](int hd) {
+        if (wave < NT) {
+            own_rows64(kfn, head_base(hd) + D, rs, own, S, half);
+            own_rows64(vfn, head_base(hd) + 2 * D, rs, own, S, half);
+        }
+        if (tid < SP) ln = tid < S ? lse[(long)hd * S + tid] : -kNegBig;
+    };
+    issue_x(bh);
+    prefetch(bh);
+    bool stored = false;  // (first head: nothing was issued after its DMA)
+    for (; bh < BH; bh += gridDim.x) {
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = kfn[s];
+            vf[s] = vfn[s];
+        }
+        float lcur = ln;
+        if (wave < NT) {
+            pin(kf);
+            pin(vf);
+        }
+        asm volatile("" : "+v"(lcur)::"memory");
+        // second-pass stores of the previous head (32 per wave with a full tile) came after this head's DMA and rows
+        if (stored && wave < NT - 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stored = true;
+        __builtin_amdgcn_s_barrier();  // Q / dO / O images complete; the K / V images are free
+        issue_y(bh);
+        if (tid < SP) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {  // same row, same physical chunk of both images = same logical chunk
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Zs + tid * ROWB + c * 16);
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(Os + tid * ROWB + c * 16);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d += (float)a[k] * (float)g[k];
+            }
+            Ls[tid] = lcur * kLog2e;  // (the exponentials below are exp2 of one FMA)
+            Ds[tid] = d;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int b = bh / H, h = bh % H;
+        bf16* dq_base = dqkv + (long)b * S * rs + h * HD;
+        bf16x8 qf[4], gf[4];
+
+        // ---- first pass: this wave's KEY tile; scores non-transposed (lane = key, regs = queries) -> dK, dV
+        if (wave < NT) {
+            f32x16 dk[2], dv[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    dk[dt][r] = 0.f;
+                    dv[dt][r] = 0.f;
+                }
+#pragma unroll 1
+            for (int qt = 0; qt < NT; ++qt) {
+                f32x16 sc, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sc[r] = 0.f;
+                    dp[r] = 0.f;
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, qt * 32 + l31, s, half), kf[s], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Os, qt * 32 + l31, s, half), vf[s], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qq = qt * 32 + acc_row(r, half);
+                    // (no key mask: a padded key only feeds its own dK / dV rows, which are never stored; padded queries
+                    // have zero Q / dO rows and a huge Ls)
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], 0.125f * kLog2e, -Ls[qq]));
+                    sc[r] = p;                     // P
+                    dp[r] = p * (dp[r] - Ds[qq]);  // dS
+                }
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const bf16x8 pa = acc_to_a(sc, blk), dsa = acc_to_a(dp, blk);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_cols(Os, qt * 32 + blk * 16, dt * 32, lane),
+                                                                        dv[dt], 0, 0, 0);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, frag_cols(Qs, qt * 32 + blk * 16, dt * 32, lane),
+                                                                        dk[dt], 0, 0, 0);
+                    }
+                }
+            }
+            // this wave's own query rows for the second pass, while the Q / dO images are still there
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                qf[s] = frag_rows(Qs, own, s, half);
+                gf[s] = frag_rows(Os, own, s, half);
+            }
+            pin(qf);
+            pin(gf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K / V images (issued a whole pass ago), before the stores below
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = wave * 32 + acc_row(r, half);
+                if (kk < S) {
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dq_base[(long)kk * rs + D + dt * 32 + l31] = (bf16)(dk[dt][r] * 0.125f);
+                        dq_base[(long)kk * rs + 2 * D + dt * 32 + l31] = (bf16)dv[dt][r];
+                    }
+                }
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // K / V complete for every wave; nobody reads the Q / dO / O images any more
+        const int nbh = bh + (int)gridDim.x;
+        if (nbh < BH) {
+            issue_x(nbh);
+            prefetch(nbh);
+        }
+        if (wave >= NT) continue;
+
+        // ---- second pass: this wave's QUERY tile; scores transposed (lane = query, regs = keys) -> dQ
+        const float lq = Ls[own], dq_row = Ds[own];
+        f32x16 dq[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x16 sc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = 0.f;
+                dp[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32 + l31, s, half), qf[s], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, kt * 32 + l31, s, half), gf[s], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // (no key mask: the K rows of padded keys are zeros, so whatever dS they get adds nothing to dQ)
+                const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], 0.125f * kLog2e, -lq));
+                dp[r] = p * (dp[r] - dq_row);
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const bf16x8 dsa = acc_to_a(dp, blk);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, frag_cols(Ks, kt * 32 + blk * 16, dt * 32, lane),
+                                                                    dq[dt], 0, 0, 0);
+            }
+        }
+        // exactly 32 store instructions per wave with a full tile (the counted wait at the top relies on it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = wave * 32 + acc_row(r, half);
             if (qq < S) {
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) dq_base[(long)qq * rs + dt * 32 + l31] = (bf16)(dq[dt][r] * 0.125f);
@@ -675,6 +1036,20 @@ void launch_bwd_kb(const void* qkv, const void* out, const void* dout, const flo
                        (const float*)dsum, (bf16*)dqkv, S, H, scale);
 }
 
+int g_pipelined = [] {  // PDT_ATTN_PIPE=0: the one-head-per-workgroup kernels for every whole-head launch
+    const char* e = getenv("PDT_ATTN_PIPE");
+    return e && e[0] == '0' ? 0 : 1;
+}();
+bool pipelined() { return g_pipelined != 0; }
+int cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
+        return v;
+    }();
+    return n;
+}
+
 bool force_generic() {
     static const bool on = [] {
         const char* e = getenv("PDT_ATTN_GENERIC");
@@ -691,6 +1066,7 @@ void set_lds(K kern, size_t bytes) {
 
 }  // namespace
 
+void set_attention_pipelined(bool on) { g_pipelined = on ? 1 : 0; }
 bool attention_shape_ok(int S, int head_dim) {
     return (head_dim == 32 || head_dim == 64 || head_dim == 128) && S >= 1 && (long)S < (1L << 24);
 }
@@ -707,6 +1083,22 @@ void launch_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, 
         return;
     }
     const int nt = (S + 31) / 32;
+    if (nt >= 5 && pipelined()) {  // 8-wave heads: persistent workgroups, LDS-DMA, the next head in flight
+        const size_t lds2 = (size_t)4 * nt * 32 * ROWB;
+        const int BH = B * H, grid = BH < cu_count() ? BH : cu_count();
+#define PDT_ATTN_FWD_P(N)                                                                                     \
+    case N: {                                                                                                 \
+        static bool once = (set_lds(&k_attn_fwd_p<N, 8>, lds2), true);                                        \
+        (void)once;                                                                                           \
+        hipLaunchKernelGGL((k_attn_fwd_p<N, 8>), dim3(grid), dim3(512), lds2, s, (const bf16*)qkv, (bf16*)out, lse, S, H, BH); \
+    } break;
+        switch (nt) {
+            PDT_ATTN_FWD_P(5) PDT_ATTN_FWD_P(6) PDT_ATTN_FWD_P(7) PDT_ATTN_FWD_P(8)
+            default: abort();
+        }
+#undef PDT_ATTN_FWD_P
+        return;
+    }
     const size_t lds = (size_t)2 * nt * 32 * ROWB;
 #define PDT_ATTN_FWD(N)                                                                                        \
     case N: {                                                                                                  \
@@ -734,6 +1126,23 @@ void launch_attention_bwd(const void* qkv, const void* out, const void* dout, co
         return;
     }
     const int nt = (S + 31) / 32;
+    if (nt >= 5 && nt <= 7 && pipelined()) {  // (8 tiles: five images do not fit the LDS)
+        const size_t lds5 = (size_t)5 * nt * 32 * ROWB + (size_t)2 * nt * 32 * sizeof(float);
+        const int BH = B * H, grid = BH < cu_count() ? BH : cu_count();
+#define PDT_ATTN_BWD_P(N)                                                                                     \
+    case N: {                                                                                                 \
+        static bool once = (set_lds(&k_attn_bwd_p<N, 8>, lds5), true);                                        \
+        (void)once;                                                                                           \
+        hipLaunchKernelGGL((k_attn_bwd_p<N, 8>), dim3(grid), dim3(512), lds5, s, (const bf16*)qkv, (const bf16*)out, \
+                           (const bf16*)dout, lse, (bf16*)dqkv, S, H, BH);                                    \
+    } break;
+        switch (nt) {
+            PDT_ATTN_BWD_P(5) PDT_ATTN_BWD_P(6) PDT_ATTN_BWD_P(7)
+            default: abort();
+        }
+#undef PDT_ATTN_BWD_P
+        return;
+    }
     const size_t lds = (size_t)4 * nt * 32 * ROWB + (size_t)2 * nt * 32 * sizeof(float);
 #define PDT_ATTN_BWD(N)                                                                                      \
     case N: {                                                                                                \

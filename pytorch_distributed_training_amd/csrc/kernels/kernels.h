@@ -138,6 +138,7 @@ void launch_layernorm_bwd(const void* dy, const void* x, const float* mean, cons
 
 // ---- fused self-attention (attention.hip): head_dim 32 / 64 / 128, any sequence length ------------------
 // (head_dim 64 up to 256 tokens runs the whole-head kernels, everything else the block-streaming ones)
+void set_attention_pipelined(bool on);  // whole-head launches of 5+ tiles: persistent pipelined kernels (default) or one head per workgroup
 bool attention_shape_ok(int S, int head_dim);
 bool attention_needs_dsum(int S, int head_dim);  // backward wants an fp32 [B,H,S] scratch (block-streaming kernels)
 // qkv [B,S,3,H,hd] bf16 -> out [B,S,H,hd] bf16, lse [B,H,S] fp32; B * H <= 65535

@@ -161,6 +161,39 @@ def test_attention_kernels(kc, shape):
     _assert_all_ok(kc, n)
 
 
+@pytest.mark.parametrize("shape", [(3, 197, 2), (40, 197, 12), (2, 129, 3), (25, 160, 12), (30, 192, 12), (23, 224, 12),
+                                   (1, 256, 2), (24, 250, 12), (1, 161, 1)])
+def test_attention_persistent_pipelined_kernels(kc, shape):
+    """Whole-head attention of 5 to 8 tiles on the persistent kernels (LDS-DMA staging, next head in flight): fewer heads
+    than CUs, several heads per workgroup (up to 480 heads on 256 CUs: uneven trip counts), full and partial last tiles;
+    against fp32, and against the one-head-per-workgroup kernels (to bf16 rounding: exp2 of one FMA instead of
+    expf of a difference, D[q] summed in a different order)."""
+    from pytorch_distributed_training_amd.ops import native
+
+    ext = pdt.require_native()
+    n = len(kc.RESULTS)
+    kc.check_attention(*shape, False)
+    _assert_all_ok(kc, n)
+    b, s_, h = shape
+    g = torch.Generator(device="cuda").manual_seed(b * 1000 + s_)
+    qkv = torch.randn(b, s_, 3 * h * 64, device="cuda", generator=g).to(torch.bfloat16)
+    do = torch.randn(b, s_, h * 64, device="cuda", generator=g).to(torch.bfloat16)
+    o1, l1 = native.attention_fwd(qkv, h)
+    d1 = native.attention_bwd(do, qkv, o1, l1, h)
+    try:
+        ext.set_attention_pipelined(False)
+        o0, l0 = native.attention_fwd(qkv, h)
+        d0 = native.attention_bwd(do, qkv, o0, l0, h)
+    finally:
+        ext.set_attention_pipelined(True)
+    assert ((o0.float() - o1.float()).abs().max() / o0.float().abs().max()) < 1e-2 and (l0 - l1).abs().max() < 1e-4
+    assert ((d0.float() - d1.float()).abs().max() / d0.float().abs().max()) < 1e-2
+    # a second pass over the same inputs gives the same bits (no dependence on which workgroup took which head)
+    o2, l2 = native.attention_fwd(qkv, h)
+    d2 = native.attention_bwd(do, qkv, o2, l2, h)
+    assert torch.equal(o1, o2) and torch.equal(d1, d2)
+
+
 @pytest.mark.parametrize("shape", [(2, 257, 2, 64), (1, 577, 3, 64), (2, 300, 2, 32), (3, 65, 1, 32), (1, 1000, 2, 128),
                                    (2, 197, 2, 128), (70, 130, 1000, 32)])
 def test_attention_block_streaming_kernels(kc, shape):
