@@ -378,6 +378,22 @@ __device__ __forceinline__ void pin(bf16x8* f) {  // the fragments exist in regi
     for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(f[s])::"memory");
 }
 
+// one bf16 through a buffer descriptor: per-lane byte offset + uniform byte offset; lanes past the descriptor's range are
+// dropped by the hardware (rows >= S of a head), so every lane issues every store and no address is kept per row
+// descriptor over [base, base + bytes) for a wave-uniform base: the two address words go through readfirstlane, because a
+// 64-bit product computed on the vector ALU (there is no scalar one) otherwise reaches the store as a VGPR pair and
+// every store gets a waterfall loop around it
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_uniform(const void* base, uint32_t bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return make_rsrc(reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo),
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)bytes));
+}
+__device__ __forceinline__ void store_bf16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (bf16)v), r, (int)voff, (int)soff, 0);
+}
+
 template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void k_attn_fwd_p(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                         float* __restrict__ lse, int S, int H, int BH) {
@@ -388,7 +404,10 @@ __global__ __launch_bounds__(64 * NW) void k_attn_fwd_p(const bf16* __restrict__
     const long D = (long)H * HD, rs = 3 * D;
     const uint32_t lds0 = lds_address(smem);
     const int q = wave * 32 + l31;  // this wave's query tile is tile `wave` of every head
-    auto head_base = [&](int bh) { return qkv + (long)(bh / H) * S * rs + (bh % H) * HD; };
+    auto head_base = [&](int bh) {
+        const int hb = __builtin_amdgcn_readfirstlane(bh / H);  // (uniform, and now the compiler knows: scalar addresses, no waterfall)
+        return qkv + (long)hb * S * rs + (bh - hb * H) * HD;
+    };
     auto issue_kv = [&](int bh, int buf) {
         const bf16* base = head_base(bh);
         stage_dma<NT, NW>(lds0 + (uint32_t)(buf * 2 * IMG), base + D, rs, S, wave, lane);
@@ -420,7 +439,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_fwd_p(const bf16* __restrict__
         if (wave >= NT) continue;
         const char* Ks = smem + buf * 2 * IMG;
         const char* Vs = Ks + IMG;
-        const int b = bh / H, h = bh % H;
+        const int b = __builtin_amdgcn_readfirstlane(bh / H), h = bh - b * H;
         // S^T tiles: rows = keys, lane = query
         f32x16 st[NT];
 #pragma unroll
@@ -477,16 +496,14 @@ __global__ __launch_bounds__(64 * NW) void k_attn_fwd_p(const bf16* __restrict__
         // exactly 33 store instructions per wave with a full tile (the counted wait above relies on it): masked lanes
         // are switched off, the instructions are issued all the same
         if (q < S && half == 0) lse[((long)b * H + h) * S + q] = m + __logf(sum);
-        bf16* orow = out + ((long)b * S * H + h) * HD;
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc_uniform(out + ((long)b * S * H + h) * HD, (uint32_t)((long)(S - 1) * D * 2 + ROWB));
+        const uint32_t ov = (uint32_t)(wave * 32 + 4 * half) * (uint32_t)(D * 2) + (uint32_t)(l31 * 2);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qr = acc_row(r, half);
-            const float invr = __shfl(inv, qr, 64);
-            const int qq = wave * 32 + qr;
-            if (qq < S) {
+            const float invr = __shfl(inv, acc_row(r, half), 64);
+            const uint32_t so = (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)(D * 2);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) orow[(long)qq * D + dt * 32 + l31] = (bf16)(o[dt][r] * invr);
-            }
+            for (int dt = 0; dt < 2; ++dt) store_bf16(ro, ov, so + dt * 64, o[dt][r] * invr);
         }
     }
 }
@@ -502,16 +519,20 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd_p(const bf16* __restrict__
     char* Zs = Os + IMG;                   // O (for D only)
     char* Ks = Zs + IMG;
     char* Vs = Ks + IMG;
-    float* Ls = reinterpret_cast<float*>(Vs + IMG);  // lse[q] * log2(e)   (huge on padding rows: P = 0 there)
-    float* Ds = Ls + SP;                             // D[q] = sum_d dO * O
+    float* Ls = reinterpret_cast<float*>(Vs + IMG);  // -8 lse[q]   (hugely negative on padding rows: P = 0 there)
+    float* Ds = Ls + SP;                             // -D[q], D[q] = sum_d dO * O
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long D = (long)H * HD, rs = 3 * D;
     const uint32_t lds0 = lds_address(smem);
     const int own = wave * 32 + l31;  // this wave's key (first pass) / query (second pass) row
-    auto head_base = [&](int bh) { return qkv + (long)(bh / H) * S * rs + (bh % H) * HD; };
+    auto head_base = [&](int bh) {
+        const int hb = __builtin_amdgcn_readfirstlane(bh / H);  // (uniform, and now the compiler knows: scalar addresses, no waterfall)
+        return qkv + (long)hb * S * rs + (bh - hb * H) * HD;
+    };
     auto issue_x = [&](int bh) {
-        const long o = ((long)(bh / H) * S * H + (bh % H)) * HD;
+        const int hb = __builtin_amdgcn_readfirstlane(bh / H);
+        const long o = ((long)hb * S * H + (bh - hb * H)) * HD;
         stage_dma<NT, NW>(lds0, head_base(bh), rs, S, wave, lane);
         stage_dma<NT, NW>(lds0 + (uint32_t)IMG, dout + o, D, S, wave, lane);
         stage_dma<NT, NW>(lds0 + (uint32_t)(2 * IMG), out + o, D, S, wave, lane);
@@ -562,13 +583,15 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd_p(const bf16* __restrict__
 #pragma unroll
                 for (int k = 0; k < 8; ++k) d += (float)a[k] * (float)g[k];
             }
-            Ls[tid] = lcur * kLog2e;  // (the exponentials below are exp2 of one FMA)
-            Ds[tid] = d;
+            Ls[tid] = -8.f * lcur;  // the score accumulators START at -8 lse[q] and -D[q]: P = exp2(c * acc) with
+            Ds[tid] = -d;           // c = log2(e) / 8, dS = P * acc', no subtraction and no L / D registers in the loops
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const int b = bh / H, h = bh % H;
-        bf16* dq_base = dqkv + (long)b * S * rs + h * HD;
+        const int b = __builtin_amdgcn_readfirstlane(bh / H), h = bh - b * H;
+        // this head's rows of dqkv: row S (the next image, or the end of the tensor) starts past the range
+        const __amdgpu_buffer_rsrc_t rd = make_rsrc_uniform(dqkv + (long)b * S * rs + h * HD, (uint32_t)((long)(S - 1) * rs * 2 + D * 4 + ROWB));
+        const uint32_t dvo = (uint32_t)(wave * 32 + 4 * half) * (uint32_t)(rs * 2) + (uint32_t)(l31 * 2);
         bf16x8 qf[4], gf[4];
 
         // ---- first pass: this wave's KEY tile; scores non-transposed (lane = key, regs = queries) -> dK, dV
@@ -583,35 +606,56 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd_p(const bf16* __restrict__
                 }
 #pragma unroll 1
             for (int qt = 0; qt < NT; ++qt) {
-                f32x16 sc, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sc[r] = 0.f;
-                    dp[r] = 0.f;
-                }
+                // every LDS read of the first two products, and this tile's L / D, in flight before the first MFMA
+                // (left alone, the compiler reads one fragment, waits, issues one MFMA: the loop then runs at LDS latency)
+                bf16x8 qa[4], ga[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, qt * 32 + l31, s, half), kf[s], sc, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Os, qt * 32 + l31, s, half), vf[s], dp, 0, 0, 0);
+                    qa[s] = frag_rows(Qs, qt * 32 + l31, s, half);
+                    ga[s] = frag_rows(Os, qt * 32 + l31, s, half);
                 }
+                f32x16 sc, dp;  // registers 4j .. 4j+3 of a tile are queries 8j + 4*half + 0..3
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qt * 32 + 8 * jj + 4 * half);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + qt * 32 + 8 * jj + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sc[4 * jj + e] = l4[e];
+                        dp[4 * jj + e] = d4[e];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[s], kf[s], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s], vf[s], dp, 0, 0, 0);
+                }
+                // the transposed fragments of the second products land while the matrix pipe and the exponentials run
+                bf16x8 oc[2][2], qc[2][2];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        oc[blk][dt] = frag_cols(Os, qt * 32 + blk * 16, dt * 32, lane);
+                        qc[blk][dt] = frag_cols(Qs, qt * 32 + blk * 16, dt * 32, lane);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int qq = qt * 32 + acc_row(r, half);
                     // (no key mask: a padded key only feeds its own dK / dV rows, which are never stored; padded queries
                     // have zero Q / dO rows and a huge Ls)
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], 0.125f * kLog2e, -Ls[qq]));
-                    sc[r] = p;                     // P
-                    dp[r] = p * (dp[r] - Ds[qq]);  // dS
+                    const float p = __builtin_amdgcn_exp2f(sc[r] * (0.125f * kLog2e));
+                    sc[r] = p;           // P
+                    dp[r] = p * dp[r];   // dS = P (dP - D)
                 }
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk) {
                     const bf16x8 pa = acc_to_a(sc, blk), dsa = acc_to_a(dp, blk);
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_cols(Os, qt * 32 + blk * 16, dt * 32, lane),
-                                                                        dv[dt], 0, 0, 0);
-                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, frag_cols(Qs, qt * 32 + blk * 16, dt * 32, lane),
-                                                                        dk[dt], 0, 0, 0);
+                        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, oc[blk][dt], dv[dt], 0, 0, 0);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, qc[blk][dt], dk[dt], 0, 0, 0);
                     }
                 }
             }
@@ -626,13 +670,11 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd_p(const bf16* __restrict__
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K / V images (issued a whole pass ago), before the stores below
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kk = wave * 32 + acc_row(r, half);
-                if (kk < S) {
+                const uint32_t so = (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)(rs * 2);
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        dq_base[(long)kk * rs + D + dt * 32 + l31] = (bf16)(dk[dt][r] * 0.125f);
-                        dq_base[(long)kk * rs + 2 * D + dt * 32 + l31] = (bf16)dv[dt][r];
-                    }
+                for (int dt = 0; dt < 2; ++dt) {
+                    store_bf16(rd, dvo, so + (uint32_t)(D * 2) + dt * 64, dk[dt][r] * 0.125f);
+                    store_bf16(rd, dvo, so + (uint32_t)(D * 4) + dt * 64, dv[dt][r]);
                 }
             }
         } else {
@@ -648,7 +690,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd_p(const bf16* __restrict__
         if (wave >= NT) continue;
 
         // ---- second pass: this wave's QUERY tile; scores transposed (lane = query, regs = keys) -> dQ
-        const float lq = Ls[own], dq_row = Ds[own];
+        const float lq = Ls[own], dq_row = Ds[own];  // (-8 lse, -D)
         f32x16 dq[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -656,40 +698,49 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd_p(const bf16* __restrict__
             for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 #pragma unroll 1
         for (int kt = 0; kt < NT; ++kt) {
+            bf16x8 ka[4], va[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                ka[s] = frag_rows(Ks, kt * 32 + l31, s, half);
+                va[s] = frag_rows(Vs, kt * 32 + l31, s, half);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 sc, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sc[r] = 0.f;
-                dp[r] = 0.f;
+                sc[r] = lq;
+                dp[r] = dq_row;
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32 + l31, s, half), qf[s], sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, kt * 32 + l31, s, half), gf[s], dp, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s], qf[s], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[s], gf[s], dp, 0, 0, 0);
             }
+            bf16x8 kc[2][2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) kc[blk][dt] = frag_cols(Ks, kt * 32 + blk * 16, dt * 32, lane);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 // (no key mask: the K rows of padded keys are zeros, so whatever dS they get adds nothing to dQ)
-                const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], 0.125f * kLog2e, -lq));
-                dp[r] = p * (dp[r] - dq_row);
+                dp[r] = __builtin_amdgcn_exp2f(sc[r] * (0.125f * kLog2e)) * dp[r];
             }
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 const bf16x8 dsa = acc_to_a(dp, blk);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, frag_cols(Ks, kt * 32 + blk * 16, dt * 32, lane),
-                                                                    dq[dt], 0, 0, 0);
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, kc[blk][dt], dq[dt], 0, 0, 0);
             }
         }
         // exactly 32 store instructions per wave with a full tile (the counted wait at the top relies on it)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qq = wave * 32 + acc_row(r, half);
-            if (qq < S) {
+            const uint32_t so = (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)(rs * 2);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) dq_base[(long)qq * rs + dt * 32 + l31] = (bf16)(dq[dt][r] * 0.125f);
-            }
+            for (int dt = 0; dt < 2; ++dt) store_bf16(rd, dvo, so + dt * 64, dq[dt][r] * 0.125f);
         }
     }
 }
