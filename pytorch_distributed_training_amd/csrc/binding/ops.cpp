@@ -581,8 +581,10 @@ Tensor conv2d_wgrad(const Tensor& dy, const Tensor& x, int64_t KH, int64_t KW, i
         if (splits > 0) {  // explicit split-K factor (tests force the multi-split slab path on small shapes)
             const long max_splits = std::max<long>(1, (nb * Ho * Wo + 31) / 32);
             g.splits = (int)std::min<long>(std::min<long>(splits, 512), max_splits);
-        } else if (nchunks > 1) {
-            g.splits = std::max<int>(1, (int)((g.splits + nchunks - 1) / nchunks));  // the chunks run back to back
+        } else if (nchunks > 1 && !gemm_tn_ok(g)) {
+            // the chunks run back to back: the small-tile kernel keeps its total workgroup count.  (The 256 x 256 kernel
+            // is one workgroup per CU per LAUNCH: dividing its splits left half the CUs idle in every chunk.)
+            g.splits = std::max<int>(1, (int)((g.splits + nchunks - 1) / nchunks));
         }
         geoms.push_back(g);
         rows += g.splits;
@@ -1494,7 +1496,9 @@ Tensor linear_wgrad(const Tensor& dy, const Tensor& x) {
     for (long m0 = 0; m0 < M; m0 += per) {
         WgradGeom g{(int)std::min(per, M - m0), 1, 1, (int)K, 1, 1, (int)N, 1, 1, 1, 0, 1};
         g.splits = conv_wgrad_splits(g);
-        if (nchunks > 1) g.splits = std::max<int>(1, (int)((g.splits + nchunks - 1) / nchunks));
+        // (gemm_tn.hip is one workgroup per CU per launch: every chunk keeps its full split count.  ViT-B/16 at
+        // B = 2560, two chunks: 135-144 workgroups per launch and 722 TFLOP/s before, see profiles/r3_attention_pipelined.md)
+        if (nchunks > 1 && !gemm_tn_ok(g)) g.splits = std::max<int>(1, (int)((g.splits + nchunks - 1) / nchunks));
         geoms.push_back(g);
         rows += g.splits;
     }

@@ -330,6 +330,31 @@ def test_gemm_identity_weight_asymmetric_input():
     assert torch.equal(c, a)
 
 
+def test_linear_wgrad_in_row_chunks_keeps_the_wide_kernel_full():
+    """A token axis longer than one buffer descriptor (ViT at a batch sized for 288 GB) goes through linear_wgrad in row
+    chunks: each chunk is its own launch of the 256 x 256 TN kernel with its full split count (round 3: the splits were
+    divided among the chunks and every launch filled half the CUs).  Same result as the single launch and as fp32."""
+    ext = pdt.require_native()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    dy = torch.randn(20000, 512, device="cuda", generator=g).to(torch.bfloat16)
+    x = torch.randn(20000, 256, device="cuda", generator=g).to(torch.bfloat16)
+    ref = dy.float().t() @ x.float()
+    ext.set_wgrad_tn_min_rows(1024)
+    try:
+        one = ext.linear_wgrad(dy, x)
+        ext.set_activation_window(8 << 20)  # 8192 rows of 1 KiB per launch: three chunks
+        try:
+            cut = ext.linear_wgrad(dy, x)
+        finally:
+            ext.set_activation_window((1 << 31) - 4096)
+    finally:
+        ext.set_wgrad_tn_min_rows(8192)
+    scale = ref.abs().mean()
+    assert ((one - ref).abs() / (ref.abs() + scale)).max() < 1e-3
+    assert ((cut - ref).abs() / (ref.abs() + scale)).max() < 1e-3
+    assert ((cut - one).abs() / (one.abs() + scale)).max() < 1e-5
+
+
 def test_linear_wgrad_and_vit_glue_kernels():
     ext = pdt.require_native()
     from pytorch_distributed_training_amd.ops import native, reference
