@@ -578,8 +578,9 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd_p(const bf16* __restrict__
             float d = 0.f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {  // same row, same physical chunk of both images = same logical chunk
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Zs + tid * ROWB + c * 16);
-                const bf16x8 g = *reinterpret_cast<const bf16x8*>(Os + tid * ROWB + c * 16);
+                const int cc = ((c + tid) & 7) * 16;  // (lanes are rows 128 B apart: rotate the chunk so that 8 lanes cover the 32 banks)
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Zs + tid * ROWB + cc);
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(Os + tid * ROWB + cc);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) d += (float)a[k] * (float)g[k];
             }
