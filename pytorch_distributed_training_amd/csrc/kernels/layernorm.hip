@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, con
     const long stride = (long)gridDim.x * 4 * R;
     for (long row0 = ((long)blockIdx.x * 4 + wave) * R; row0 < M; row0 += stride) {
         float xh[R][NP][4], gg[R][NP][4], s1[R], s2[R], rs_[R];
+        bf16x4 ta[R][NP];  // the residual-path gradient, fetched with x and dy (not after the reductions)
         bool live[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, con
             live[r] = row < M;
             const bf16x4* xr = reinterpret_cast<const bf16x4*>(x + row * D);
             const bf16x4* dr = reinterpret_cast<const bf16x4*>(dy + row * D);
+            const bf16x4* ar = reinterpret_cast<const bf16x4*>(addend + row * D);
             const float mu = live[r] ? mean[row] : 0.f;
             rs_[r] = live[r] ? rstd[row] : 0.f;
             s1[r] = 0.f;
@@ -113,9 +115,11 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, con
             for (int j = 0; j < NP; ++j) {
                 const bool in = live[r] && lane + 64 * j < np4;
                 bf16x4 tx = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, td = tx;
+                ta[r][j] = tx;
                 if (in) {
                     tx = xr[lane + 64 * j];
                     td = dr[lane + 64 * j];
+                    if (addend) ta[r][j] = ar[lane + 64 * j];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -138,19 +142,12 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16* __restrict__ dy, con
             bf16x4* ox = reinterpret_cast<bf16x4*>(dx + row * D);
             // the gradient that reaches the same tensor through the residual connection joins here (pre-LN
             // transformer block: d(x) = d(skip) + LN'(d(branch))) instead of in a separate elementwise add
-            const bf16x4* ar = addend ? reinterpret_cast<const bf16x4*>(addend + row * D) : nullptr;
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 if (lane + 64 * j >= np4) break;
                 bf16x4 o;
-                if (ar) {
-                    const bf16x4 ta = ar[lane + 64 * j];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = (bf16)(rs * (gg[r][j][k] - c1 - xh[r][j][k] * c2) + (float)ta[k]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = (bf16)(rs * (gg[r][j][k] - c1 - xh[r][j][k] * c2));
-                }
+                for (int k = 0; k < 4; ++k) o[k] = (bf16)(rs * (gg[r][j][k] - c1 - xh[r][j][k] * c2) + (float)ta[r][j][k]);  // (zeros without an addend)
                 ox[lane + 64 * j] = o;
             }
         }
