@@ -777,13 +777,25 @@ struct AttnGeo {
     }
     // rows [r0, r0 + 64) of a [*, row_stride] tensor -> LDS image rows 0..63 (zeros past S); 256 threads
     static __device__ __forceinline__ void stage64(char* img, const bf16* src, long row_stride, int r0, int S, int tid) {
-        for (int i = tid; i < 64 * NCH; i += 256) {
-            const int row = i / NCH, ch = i % NCH;
-            bf16x8 v;
+        // every load of the block is issued before the first LDS store (a load -> wait -> store loop pays the memory
+        // latency once per chunk); rows past S read row S - 1 and are zeroed by a select, so no load sits behind a branch
+        constexpr int IT = 64 * NCH / 256;
+        static_assert(IT >= 1 && 64 * NCH % 256 == 0, "a block is a whole number of chunks per thread");
+        bf16x8 v[IT];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = (bf16)0.f;
-            if (r0 + row < S) v = *reinterpret_cast<const bf16x8*>(src + (long)(r0 + row) * row_stride + ch * 8);
-            *reinterpret_cast<bf16x8*>(img + swz(row, ch)) = v;
+        for (int t = 0; t < IT; ++t) {
+            const int i = tid + 256 * t, row = i / NCH, ch = i % NCH;
+            const int rr = r0 + row < S ? r0 + row : S - 1;
+            v[t] = *reinterpret_cast<const bf16x8*>(src + (long)rr * row_stride + ch * 8);
+        }
+#pragma unroll
+        for (int t = 0; t < IT; ++t) {
+            const int i = tid + 256 * t, row = i / NCH, ch = i % NCH;
+            if (r0 + row >= S) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[t][k] = (bf16)0.f;
+            }
+            *reinterpret_cast<bf16x8*>(img + swz(row, ch)) = v[t];
         }
     }
     // a wave's own 32 rows as MFMA fragments straight from global memory (lane = row, 8 elements per step and half)
