@@ -493,8 +493,9 @@ __global__ __launch_bounds__(64 * NW) void k_attn_fwd_p(const bf16* __restrict__
                                                                    o[dt], 0, 0, 0);
             }
         const float inv = 1.f / sum;
-        // exactly 33 store instructions per wave with a full tile (the counted wait above relies on it): masked lanes
-        // are switched off, the instructions are issued all the same
+        // a wave with a full tile issues 33 stores here, after the next head's DMA: "at most 33 outstanding" at the top of
+        // the loop therefore means that DMA has landed (the count may only be exceeded, never undercut: the buffer
+        // stores below are issued for every row, rows past S are dropped by the descriptor)
         if (q < S && half == 0) lse[((long)b * H + h) * S + q] = m + __logf(sum);
         const __amdgpu_buffer_rsrc_t ro = make_rsrc_uniform(out + ((long)b * S * H + h) * HD, (uint32_t)((long)(S - 1) * D * 2 + ROWB));
         const uint32_t ov = (uint32_t)(wave * 32 + 4 * half) * (uint32_t)(D * 2) + (uint32_t)(l31 * 2);
@@ -736,7 +737,8 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd_p(const bf16* __restrict__
                     dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, kc[blk][dt], dq[dt], 0, 0, 0);
             }
         }
-        // exactly 32 store instructions per wave with a full tile (the counted wait at the top relies on it)
+        // 32 stores per wave, issued for every row (rows past S are dropped by the descriptor): the counted wait at the top
+        // of the loop needs at least that many operations behind the next head's DMA
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const uint32_t so = (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)(rs * 2);
