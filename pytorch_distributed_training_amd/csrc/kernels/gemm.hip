@@ -357,10 +357,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
             }
         }
 
+        // The tile leaves in two halves of 128 rows (64 KiB staged at a time).  A half is the rows EVERY wave holds in
+        // four of its eight row groups (tile rows 64 hh .. + 63 and 128 + 64 hh .. + 63), so all 8 waves convert and
+        // stage at once; with "half = the rows of waves 0-3 / 4-7" the four other waves waited through each staging
+        // (PDT_GEMM_STAGE_BY_WAVE builds that older form).  grow(): tile row of staged row lr.
+#ifdef PDT_GEMM_STAGE_BY_WAVE
+        constexpr bool BY_I = false;
+#else
+        constexpr bool BY_I = true;
+#endif
+        auto grow = [&](int hh, int lr) { return BY_I ? hh * 64 + (lr & 63) + ((lr >> 6) << 7) : hh * 128 + lr; };
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             if (a.debug_nostore & 2) break;  // (timing diagnostics: no staging, no row pass)
-            if (wr == hh) {
+            if (BY_I || wr == hh) {
                 // lane holds, for 16x16 tile (i, j): row i*16 + lane%16, columns j*16 + (lane/16)*4 + 0..3
                 const int wcol = wc * (BNT / 4) + lq * 4;
 #pragma unroll
@@ -369,10 +379,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                     const int n = on0 + wcol + j * 16;
                     if (CONV == 0 && a.bias != nullptr && n < a.N) bv = *reinterpret_cast<const f32x4_t*>(a.bias + n);  // N % 4 == 0
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
+                    for (int ii = 0; ii < (BY_I ? 4 : 8); ++ii) {
+                        const int i = BY_I ? hh * 4 + ii : ii;                  // accumulator row group
+                        const int srow = (BY_I ? wr * 64 : 0) + ii * 16 + l15;  // staged row
                         const f32x4_t v = acc[i][j] + bv;
                         const bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        *reinterpret_cast<bf16x4*>(Os + (i * 16 + l15) * OPITCH_T +
+                        *reinterpret_cast<bf16x4*>(Os + srow * OPITCH_T +
                                                    (((wc * (BNT / 32) + j * 2 + (lq >> 1)) ^ (l15 & 7)) << 4) +
                                                    (((lq & 1) ^ (l15 >> 3)) << 3)) = pk;
                     }
@@ -390,13 +402,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
                 uint32_t coff[PB];
 #pragma unroll
                 for (int p = 0; p < PB; ++p) {
-                    const int row = hh * 128 + (pb + p) * RPP + orow;
+                    const int row = grow(hh, (pb + p) * RPP + orow);
                     coff[p] = col_ok ? (uint32_t)row * (uint32_t)(a.ldc * 2) + (uint32_t)(ncol * 2) : kOOB;
                 }
                 if (EXTRA != 0 || CONV == 2) {
 #pragma unroll
                     for (int p = 0; p < PB; ++p) {
-                        const int row = hh * 128 + (pb + p) * RPP + orow;
+                        const int row = grow(hh, (pb + p) * RPP + orow);
                         const uint32_t eo = col_ok ? (uint32_t)row * (uint32_t)(lde * 2) + (uint32_t)(ncol * 2) : kOOB;
                         if (EXTRA != 0 || has_add) ev[p] = buffer_load_bf16x8_stream(re, eo);
                         if (CONV == 2) {
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)ev[p][k]);
                     }
-                    if (COLSUM && hh * 128 + lrow < orows_m) {
+                    if (COLSUM && grow(hh, lrow) < orows_m) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) csum[k] += (float)v[k];
                     }
