@@ -1314,6 +1314,27 @@ def test_hip_graph_step_matches_eager(opt, gd):
     assert runs[1][-2] < runs[1][0] and runs[1][-1] < runs[1][1], runs
 
 
+def test_hip_graph_vit_step_matches_eager():
+    """A ViT step (197 tokens: the persistent pipelined attention kernels, LayerNorm, the GEMM core with every fused
+    epilogue, AdamW) captured in one hipGraph replays to the eager losses; no library fallback in either run."""
+    from pytorch_distributed_training_amd.nn import functional as pF
+
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.rand(6, 3, 224, 224, generator=g).cuda() for _ in range(2)] * 4
+    ys = [torch.randint(0, 10, (6,), generator=g).cuda() for _ in range(2)] * 4
+    before = dict(pF.fallback_counts)
+    runs = []
+    for graph in (False, True):
+        eng = _engine(model="vit_ti_16", num_classes=10, optimizer="adamw", lr=1e-3, graph=graph, image_size=224)
+        eng.optimizer.set_capturable(True)
+        runs.append([float(eng.train_step(x, y)) for x, y in zip(xs, ys)])
+        if graph:
+            assert eng._graph is not None, eng._graph_failed
+    assert dict(pF.fallback_counts) == before, dict(pF.fallback_counts)
+    assert runs[0] == pytest.approx(runs[1], rel=5e-3), runs
+    assert runs[1][-2] < runs[1][0], runs
+
+
 def test_batch_chunking_beyond_the_descriptor_window_matches_single_launches(kc):
     """Activations larger than one buffer descriptor (2 GiB: B > 1337 at 224x224) run as several launches over
     batch chunks.  The window is shrunk to 192 KiB so that small tensors take that path: outputs that do not
