@@ -146,11 +146,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(const GemmArgs a) {
     }
     auto setup = [&](int idx) {
         // grouped order: bands of a.group_m tile rows, m fastest inside a band (group_m = 1: n fastest)
+        // (divisions by launch constants through multiply-high: two integer divisions by run-time values cost ~1 000
+        // shader clocks here, once per tile, a tenth of a short-K tile)
         const int band_tiles = a.group_m * a.n_tiles;
-        const int band = idx / band_tiles, rem = idx - band * band_tiles;
-        int band_rows = a.m_tiles - band * a.group_m;
-        band_rows = band_rows < a.group_m ? band_rows : a.group_m;
-        const int tn = rem / band_rows;
+        const int band = (int)fdiv((uint32_t)idx, a.div_band), rem = idx - band * band_tiles;
+        const bool last = band == a.last_band;
+        const int band_rows = last ? a.last_rows : a.group_m;
+        const int tn = (int)(last ? fdiv((uint32_t)rem, a.div_last) : fdiv((uint32_t)rem, a.div_gm));
         tile_m = band * a.group_m + (rem - tn * band_rows);
         m0 = (long)tile_m * BM;
         n0 = tn * BNT;
@@ -592,6 +594,11 @@ static void launch_width(GemmArgs& a, int cus, hipStream_t s) {
     // 32 tiles run together on one XCD: with many tile columns walk bands of 4 tile rows (4 A panels + 8 B panels
     // per K-step instead of 1 + 32)
     a.group_m = a.n_tiles > 12 ? 4 : 1;
+    a.last_band = (a.m_tiles - 1) / a.group_m;
+    a.last_rows = a.m_tiles - a.last_band * a.group_m;
+    a.div_band = make_fastdiv((uint32_t)(a.group_m * a.n_tiles));
+    a.div_gm = make_fastdiv((uint32_t)a.group_m);
+    a.div_last = make_fastdiv((uint32_t)a.last_rows);
     const int total = a.m_tiles * a.n_tiles;
     const int grid = total < cus ? total : cus;
     const bool ragged = a.K % BK != 0, colsum = a.colsum_slab != nullptr;

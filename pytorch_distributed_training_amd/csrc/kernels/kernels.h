@@ -282,6 +282,8 @@ struct GemmArgs {
     int a_stream;  // (set by launch_gemm_nt) one tile column: A is read exactly once -> non-temporal DMA
     int32_t tap[9];  // (dh & 0xff) | (dw & 0xff) << 8 | wslot << 16
     FastDiv div_w, div_hw, div_kt;  // / W, / (H * W), / (K / 64)
+    FastDiv div_band, div_gm, div_last;  // (launcher) tile index -> band / row in a full band / row in the last band
+    int last_band, last_rows;            // (launcher) index of the last band of tile rows and its row count
     int bn;                         // tile width: 0 = the launcher picks (gemm_tile_width), 128 or 256
     int m_tiles, n_tiles, group_m;  // filled by the launcher
     int debug_nostore;              // timing diagnostics, bit mask: 1 output stores dropped (zero-size descriptor),
