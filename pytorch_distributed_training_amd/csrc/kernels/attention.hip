@@ -726,8 +726,12 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd_p(const bf16* __restrict__
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // (no key mask: the K rows of padded keys are zeros, so whatever dS they get adds nothing to dQ)
-                dp[r] = __builtin_amdgcn_exp2f(sc[r] * (0.125f * kLog2e)) * dp[r];
+                // No key mask, but P is clamped to [0, 1]: the K rows of padded keys are zeros, so whatever FINITE dS
+                // they get adds nothing to dQ -- their score is 0, though, and with lse < -88 (scores that are all
+                // strongly negative) exp(0 - lse) overflows to inf, inf * 0 = NaN (found by a diverging ViT run,
+                // profiles/r3_convergence_vit.md).  For real keys P <= 1 up to rounding; the clamp rides on v_exp_f32.
+                const float p = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(sc[r] * (0.125f * kLog2e)), 0.f, 1.f);
+                dp[r] = p * dp[r];
             }
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {

@@ -194,6 +194,38 @@ def test_attention_persistent_pipelined_kernels(kc, shape):
     assert torch.equal(o1, o2) and torch.equal(d1, d2)
 
 
+@pytest.mark.parametrize("S,hd", [(197, 64), (130, 64), (64, 64), (300, 64), (197, 128)])
+def test_attention_with_log_sum_exp_far_below_zero(S, hd):
+    """Scores that are ALL strongly negative (lse < -88): exp(0 - lse) of a padded key's zero score overflows fp32.  The
+    padded keys must not leak inf * 0 = NaN into dQ (the pipelined backward did, in a diverging ViT run:
+    profiles/r3_convergence_vit.md); every kernel family against fp32."""
+    from pytorch_distributed_training_amd.ops import native, reference
+
+    ext = pdt.require_native()
+    H = 2
+    g = torch.Generator(device="cuda").manual_seed(S + hd)
+    a = 3.5 * (64.0 / hd) ** 0.25  # q . k / sqrt(hd) ~ -98 for every pair
+    q = a + 0.05 * torch.randn(3, S, H * hd, device="cuda", generator=g)
+    k = -a + 0.05 * torch.randn(3, S, H * hd, device="cuda", generator=g)
+    v = torch.randn(3, S, H * hd, device="cuda", generator=g)
+    qkv = torch.cat([q, k, v], dim=-1).to(torch.bfloat16)
+    do = torch.randn(3, S, H * hd, device="cuda", generator=g).to(torch.bfloat16)
+    outr, lser = reference.attention_fwd(qkv.float(), H)
+    assert float(lser.max()) < -88.0
+    dr = reference.attention_bwd(do.float(), qkv.float(), outr, lser, H)
+    for pipelined in (True, False):
+        ext.set_attention_pipelined(pipelined)
+        try:
+            out, lse = native.attention_fwd(qkv, H)
+            d = native.attention_bwd(do, qkv, out, lse, H)
+        finally:
+            ext.set_attention_pipelined(True)
+        assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(d.float()).all()), pipelined
+        assert ((out.float() - outr).abs().max() / outr.abs().max()) < 2e-2
+        assert (lse - lser).abs().max() < 1e-2
+        assert ((d.float() - dr).abs().max() / dr.abs().max()) < 3e-2, pipelined
+
+
 @pytest.mark.parametrize("shape", [(2, 257, 2, 64), (1, 577, 3, 64), (2, 300, 2, 32), (3, 65, 1, 32), (1, 1000, 2, 128),
                                    (2, 197, 2, 128), (70, 130, 1000, 32)])
 def test_attention_block_streaming_kernels(kc, shape):
