@@ -647,7 +647,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bwd_p(const bf16* __restrict__
                 for (int r = 0; r < 16; ++r) {
                     // (no key mask: a padded key only feeds its own dK / dV rows, which are never stored; padded queries
                     // have zero Q / dO rows and a huge Ls)
-                    const float p = __builtin_amdgcn_exp2f(sc[r] * (0.125f * kLog2e));
+                    const float p = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(sc[r] * (0.125f * kLog2e)), 0.f, 1.f);  // (clamp: free on v_exp_f32)
                     sc[r] = p;           // P
                     dp[r] = p * dp[r];   // dS = P (dP - D)
                 }
