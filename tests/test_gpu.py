@@ -262,6 +262,86 @@ def test_attention_block_streaming_equals_whole_head_kernels():
         assert ((a - b).abs().max() / a.abs().max().clamp_min(1e-6)) < tol, k
 
 
+def _close(a, b, tol, what):
+    a, b = a.float(), b.float()
+    assert bool(torch.isfinite(a).all()), f"{what}: non-finite values"
+    err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+    assert err < tol, (what, err)
+
+
+def test_kernels_on_extreme_but_legal_inputs():
+    """What random-normal test data never shows: constant rows (zero variance), a residual stream in the hundreds,
+    logits far apart, a softmax with one overwhelming key, GELU far into both tails, channels that are constant over
+    the batch.  Every output finite and equal to the fp32 reference of the same inputs."""
+    from pytorch_distributed_training_amd.ops import native, reference
+
+    g = torch.Generator(device="cuda").manual_seed(77)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    # LayerNorm: constant rows, a large offset with small spread, values near the top of what bf16 activations reach
+    x = rn(300, 768)
+    x[0:8] = 3.0
+    x[8:16] = 250.0 + 0.5 * rn(8, 768)
+    x[16:24] = 3.0e4 * rn(8, 768)
+    x = x.to(torch.bfloat16)
+    gamma, beta = torch.rand(768, device="cuda", generator=g) + 0.5, 0.1 * rn(768)
+    y, mean, rstd = native.layernorm_fwd(x, gamma, beta, 1e-6)
+    yr, mr, rr = reference.layernorm_fwd(x, gamma, beta, 1e-6)
+    _close(y, yr, 2e-2, "layernorm y")
+    _close(rstd, rr, 1e-3, "layernorm rstd")
+    dy, add = rn(300, 768).to(torch.bfloat16), rn(300, 768).to(torch.bfloat16)
+    for got, want, what in zip(native.layernorm_bwd(dy, x, mr, rr, gamma, add), reference.layernorm_bwd(dy, x, mr, rr, gamma, add),
+                               ("dx", "dgamma", "dbeta")):
+        _close(got, want, 2e-2, "layernorm " + what)
+    # softmax cross-entropy: logits hundreds apart, the label on the smallest one
+    logits = (40.0 * rn(64, 1000)).to(torch.bfloat16)
+    labels = logits.float().argmin(dim=1)
+    loss, dl = native.softmax_ce_fwd_bwd(logits, labels)
+    lossr, dlr = reference.softmax_ce_fwd_bwd(logits, labels)
+    _close(loss, lossr, 1e-3, "softmax-CE loss")
+    _close(dl, dlr, 2e-2, "softmax-CE gradient")
+    # attention: one key that dwarfs the rest (scores ~ +-400), and keys / queries of very different norms
+    qkv = rn(2, 197, 3 * 2 * 64)
+    qkv[:, :, :128] *= 6.0
+    qkv[:, 5, 128:256] *= 8.0
+    qkv = qkv.to(torch.bfloat16)
+    do = rn(2, 197, 128).to(torch.bfloat16)
+    out, lse = native.attention_fwd(qkv, 2)
+    outr, lser = reference.attention_fwd(qkv.float(), 2)
+    _close(out, outr, 2e-2, "attention out")
+    _close(lse, lser, 1e-3, "attention lse")
+    _close(native.attention_bwd(do, qkv, out, lse, 2), reference.attention_bwd(do.float(), qkv.float(), outr, lser, 2), 4e-2,
+           "attention dqkv")
+    # GEMM epilogues: GELU and GELU' far into both tails, a bias that dominates the product
+    a = (3.0 * rn(512, 256)).to(torch.bfloat16)
+    w = rn(512, 256).to(torch.bfloat16)
+    bias = 50.0 * rn(512)
+    c, pre, _ = native.gemm_nt(a, w, bias=bias, act=1, want_preact=True)
+    cr, prer, _ = reference.gemm_nt(a, w, bias=bias, act=1, want_preact=True)
+    _close(pre, prer, 2e-2, "gemm pre-activation")
+    _close(c, cr, 2e-2, "gemm GELU")
+    u = (60.0 * rn(512, 512)).to(torch.bfloat16)
+    d, _, cs = native.gemm_nt(a, w, gelu_in=u, want_colsum=True)
+    dr_, _, csr = reference.gemm_nt(a, w, gelu_in=u, want_colsum=True)
+    _close(d, dr_, 2e-2, "gemm x GELU'")
+    _close(cs, csr, 2e-2, "gemm column sums")
+    # BatchNorm: a channel that is constant over the batch, a channel with a huge offset
+    xb = rn(8, 64, 14, 14)
+    xb[:, 3] = 1.25
+    xb[:, 5] += 1000.0
+    xb = xb.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    st = native.bn_stats(xb)
+    mean_, invstd = native.bn_finalize(st, float(8 * 14 * 14), 1e-5)
+    meanr, invstdr = reference.bn_finalize(reference.bn_stats(xb), float(8 * 14 * 14), 1e-5)
+    _close(mean_, meanr, 1e-3, "bn mean")
+    assert bool(torch.isfinite(invstd).all()) and float(invstd[3]) == pytest.approx(1e-5 ** -0.5, rel=1e-2)
+    # (channel 5: var 1 next to mean 1000 in bf16 steps of 8 -- both paths see the same rounded data)
+    _close(invstd, invstdr, 2e-2, "bn invstd")
+    one, zero = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+    yb = native.bn_apply_act(xb, mean_, invstd, one, zero, relu=True)
+    ybr = reference.bn_apply_act(xb, meanr, invstdr, one, zero, relu=True)
+    _close(yb[0] if isinstance(yb, tuple) else yb, ybr[0] if isinstance(ybr, tuple) else ybr, 3e-2, "bn apply")
+
+
 @pytest.mark.parametrize("shape", [(5, 768), (592, 256), (1030, 1024), (8 * 197, 768), (77, 32), (300, 192), (129, 384),
                                    (64, 1536), (33, 2048), (10, 100)])
 def test_layernorm_kernels(kc, shape):
