@@ -1,6 +1,7 @@
 // Fused multi-head self-attention (forward + backward) on the gfx950 matrix cores, no mask, no dropout.
-// Two families: whole-head kernels for short sequences at head_dim 64 (ViT-B/16: 197 tokens; the flagship path),
-// and key-/query-block streaming kernels for any length at head_dim 32 / 64 / 128 (second half of the file).
+// Three families: whole-head kernels for short sequences at head_dim 64, one head per workgroup (up to 128 tokens) or,
+// from 129 tokens on, persistent and software-pipelined (ViT-B/16: 197 tokens; the flagship path, middle of the file);
+// and key-/query-block streaming kernels for any length at head_dim 32 / 64 / 128 (last part of the file).
 //
 //   qkv : [B, S, 3, H, 64] bf16  (the packed in-projection output, read in place: no permute copies)
 //   out : [B, S, H, 64]    bf16  (= [B, S, D], what the out-projection GEMM wants)
