@@ -1080,6 +1080,38 @@ def test_two_engine_ranks_on_one_gpu_train_to_identical_replicas(tmp_path, syncb
     assert outs[0]["bn_mean0"] == outs[1]["bn_mean0"], outs  # running statistics: same bits on both ranks
 
 
+@pytest.mark.parametrize("grad_comm", ["rccl", "ipc"])
+def test_two_vit_ranks_on_one_gpu_train_to_identical_replicas(tmp_path, grad_comm):
+    """The same W = 2 rehearsal with a transformer under the reducer (ViT-Ti/16 at 224 x 224: 150 parameter tensors,
+    AdamW, the persistent attention kernels of both ranks sharing the CUs): gradient buckets through the host-staged
+    group or through the two-shot direct all-reduce over IPC windows; the loss falls and the replicas hold the same bits."""
+    procs = []
+    port = str(29660 + (1 if grad_comm == "ipc" else 0))
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PDT_TEST_DEADLINE_S="100", PDT_QUIET="1", PDT_GRAD_COMM=grad_comm,
+                   PDT_TEST_MODEL="vit_ti_16", PDT_TEST_STEPS="6")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "bench", "micro", "engine_w2_worker.py")],
+                                      env=env, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=150)
+            assert p.returncode == 0, se[-3000:]
+            outs.append(json.loads(so.strip().splitlines()[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    outs.sort(key=lambda o: o["rank"])
+    assert [o["world"] for o in outs] == [2, 2] and all(o["reducer"] == "native" for o in outs), outs
+    if grad_comm == "ipc":
+        assert all(o["grad_comm"]["path"] == "ipc" and o["ipc_bucket_launches"] >= 6 for o in outs), outs
+    l0 = outs[0]["losses"]
+    assert all(v == v for v in l0) and l0[-1] < l0[0], l0
+    assert outs[0]["param_sum"] == outs[1]["param_sum"], outs
+
+
 def test_loader_sends_uint8_batches_and_the_cast_kernel_matches_the_fp32_path():
     """The loader's GPU path: uint8 NHWC through the pinned ring and the copy stream, /255 + bf16 + layout in the
     engine's one cast kernel; same tensor as the fp32 NCHW path gives, same order, short last batch."""
